@@ -1,0 +1,194 @@
+/*
+ * libunet_hip.so -- C-ABI of the MI355X-native U-Net anomaly-segmentation hot path.
+ *
+ * The reference (ukeSJTU/tiaozhanbei-unet) has no FFI: its hot path is reached through
+ * Python objects (src/model.py, src/train_utils.py) and the arithmetic lives in ATen.
+ * This header is the boundary BELOW those Python objects: every entry point names the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types.  All device tensors are dense NHWC
+ *     ("channels last": [N][H][W][C], C fastest) in the compute dtype (UNET_F32 or
+ *     UNET_BF16) unless a parameter says otherwise; parameters/gradients of the model
+ *     are fp32 in PyTorch's own layouts (OIHW etc.).
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library keeps no
+ *     device state, never allocates or frees device memory and never synchronises:
+ *     all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - return value: UNET_OK (0) or a negative unet_status; unet_last_error() gives the
+ *     thread-local text of the last failure.  No C++ exception crosses the ABI.
+ *   - `unet_view` places an NHWC tensor inside a larger logical frame: it is how the
+ *     skip-concat (`torch.cat([x2, x1], 1)`, src/model.py:65) and the centre pad
+ *     (`F.pad`, src/model.py:57-61) are expressed without ever materialising them.
+ */
+#ifndef UNET_HIP_H_
+#define UNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_ABI_VERSION 1
+
+enum unet_dtype { UNET_F32 = 0, UNET_BF16 = 1 };
+
+enum unet_status {
+  UNET_OK = 0,
+  UNET_ERR_BAD_ARG = -1,      /* null pointer / negative size / inconsistent description */
+  UNET_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover (see each function)  */
+  UNET_ERR_WORKSPACE = -3,    /* workspace too small                                        */
+  UNET_ERR_LAUNCH = -4        /* HIP reported a launch error (text in unet_last_error)      */
+};
+
+/* An NHWC tensor [n][h][w][c] whose pixel (0,0) sits at (off_y, off_x) of a logical frame.
+ * Reads outside the tensor give 0; writes outside are dropped. */
+typedef struct unet_view {
+  void* ptr;
+  int32_t c;
+  int32_t h, w;
+  int32_t off_y, off_x;
+} unet_view;
+
+int32_t unet_abi_version(void);
+const char* unet_last_error(void);
+
+/* ---- per-kernel-class timing (used by bench.py for the roofline object) -------------- */
+enum unet_kclass {
+  UNET_K_CONV_FWD = 0, UNET_K_CONV_DGRAD, UNET_K_CONV_WGRAD, UNET_K_CONVT_FWD, UNET_K_CONVT_DGRAD,
+  UNET_K_CONVT_WGRAD, UNET_K_BN, UNET_K_POOL, UNET_K_HEAD, UNET_K_LOSS, UNET_K_PACK, UNET_K_OTHER,
+  UNET_K_COUNT
+};
+/* When enabled, every launch of a timed class is bracketed by hipEvents on its own stream. */
+int32_t unet_prof_enable(int32_t on);
+/* Synchronises the recorded events; fills ms[UNET_K_COUNT], launches[UNET_K_COUNT],
+ * flops[UNET_K_COUNT] (algorithmic FLOPs summed over the launches) and clears the log. */
+int32_t unet_prof_collect(double* ms, int64_t* launches, double* flops);
+
+/* ---- layout ------------------------------------------------------------------------- */
+/* NCHW fp32 -> NHWC compute dtype with the channel dim zero-padded to c_pad
+ * (the `.to(device)` batch of src/train_utils.py:118 entering src/model.py:190). */
+int32_t unet_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                          int32_t c_pad, int32_t dtype, void* stream);
+/* NHWC compute dtype (row stride c_pad) -> NCHW fp32, first c channels. */
+int32_t unet_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                          int32_t c_pad, int32_t dtype, void* stream);
+
+/* ---- weight packing: fp32 parameters -> GEMM operand layouts in the compute dtype ------ */
+enum unet_pack_mode {
+  UNET_PACK_CONV_FWD = 0,   /* Conv2d w[co][ci][3][3]   -> [9][co_rows][ci_k]            */
+  UNET_PACK_CONV_DGRAD = 1, /* same weight              -> [9 flipped][ci_rows][co_k]    */
+  UNET_PACK_CONVT_FWD = 2,  /* ConvTranspose2d w[ci][co][2][2] -> [4][co_rows][ci_k]     */
+  UNET_PACK_CONVT_DGRAD = 3 /* same weight              -> [ci_rows][4*co_k]             */
+};
+/* rows / k are the padded GEMM dims (zero filled); c_out, c_in are the parameter's dims. */
+int32_t unet_pack_weight(const float* w, void* out, int32_t c_out, int32_t c_in, int32_t rows,
+                         int32_t k, int32_t mode, int32_t dtype, void* stream);
+
+/* ---- 3x3 convolution, pad 1, stride 1, no bias (nn.Conv2d at src/model.py:14,17) ------ */
+/* y = conv(concat(src[0], src[1])) as an implicit GEMM on MFMA.  Output channels below
+ * dst_split go to dst[0], the rest to dst[1] (dst[1].ptr may be NULL when dst_split == c_out).
+ * The same entry computes the data gradient when given UNET_PACK_CONV_DGRAD weights:
+ * dX = conv(dY, flipped W^T).  `accumulate` adds into dst (gradient fan-in of the skips).
+ * Requires: channel counts of each src multiples of 64 (or a single src of 8/16 for the
+ * image layer), c_out multiple of 64. */
+int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                     const void* w_packed, int32_t c_out, const unet_view dst[2], int32_t dst_split,
+                     int32_t accumulate, int32_t kclass, void* stream);
+
+/* dW[co][ci][3][3] (fp32, OIHW) = sum over pixels of dY (x) shifted X; split-K over pixel
+ * tiles with fp32 partial slabs in `workspace`, reduced in a fixed order (deterministic).
+ * (autograd of nn.Conv2d, reached from total_loss.backward() at src/train_utils.py:132) */
+size_t unet_conv3x3_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                           const void* dy, int32_t c_out, float* dw, int32_t c_in_param,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- 2x2 stride-2 transposed convolution with bias (nn.ConvTranspose2d, src/model.py:51) */
+/* y[n][2i+k][2j+l][co] = b[co] + sum_ci x[n][i][j][ci] * w[ci][co][k][l]  (one GEMM + pixel shuffle) */
+int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x, int32_t c_in,
+                          const void* w_packed, const float* bias, void* y, int32_t c_out, void* stream);
+/* dx from dy (dy is the [n][2h][2w][c_out] gradient); w_packed = UNET_PACK_CONVT_DGRAD. */
+int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy,
+                            int32_t c_out, const void* w_packed, void* dx, int32_t c_in, void* stream);
+size_t unet_convt2x2_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+/* dw[ci][co][2][2], db[co] in fp32. */
+int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x, int32_t c_in,
+                            const void* dy, int32_t c_out, float* dw, float* db, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d (+ ReLU) (nn.BatchNorm2d / nn.ReLU at src/model.py:15-16,18-19) -------- */
+size_t unet_bn_workspace(int64_t pixels, int32_t c);
+/* training statistics of y[pixels][c]: biased variance for normalisation, running stats
+ * updated with `momentum` towards mean / UNBIASED variance (running_* may be NULL).
+ * Outputs (fp32[c]): save_mean, save_istd, scale = gamma*istd, shift = beta - mean*scale. */
+int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pixels, int32_t c, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum,
+                            float eps, float* save_mean, float* save_istd, float* scale, float* shift,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* eval: scale/shift from the running statistics. */
+int32_t unet_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* a = max(fma(y, scale, shift), 0) */
+int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixels, int32_t c, const float* scale,
+                           const float* shift, void* a, void* stream);
+/* backward of a = relu(bn(y)) in training mode: dgamma, dbeta (fp32[c]) and
+ * dy = gamma*istd*(dz - dbeta/M - yhat*dgamma/M), dz = da*[z>0]. */
+int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                         const float* gamma, const float* save_mean, const float* save_istd,
+                         const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- MaxPool2d(2) (src/model.py:32): stride 2, floor; first maximum wins ties ---------- */
+int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c,
+                          void* y, void* stream);
+int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* dy, int32_t n, int32_t h, int32_t w,
+                          int32_t c, void* dx, void* stream);
+
+/* ---- bilinear x2, align_corners=True (nn.Upsample, src/model.py:48) -------------------- */
+int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,
+                                     int32_t c, void* y, void* stream);
+int32_t unet_upsample_bilinear2x_bwd(int32_t dtype, const void* dy, int32_t n, int32_t h, int32_t w,
+                                     int32_t c, void* dx, void* stream);
+
+/* ---- 1x1 head (OutConv, src/model.py:72) with optional sigmoid (src/model.py:201,208) --- */
+/* x: NHWC compute dtype [pixels][c_in]; w fp32 [c_out][c_in]; out: NCHW fp32. c_out <= 8. */
+int32_t unet_head_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c_in,
+                      const float* weight, const float* bias, int32_t c_out, int32_t sigmoid, float* out,
+                      void* stream);
+size_t unet_head_bwd_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+/* dout: NCHW fp32 gradient w.r.t. `out`; out: the forward result (needed when sigmoid). */
+int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out, const float* dout, int32_t n,
+                      int32_t h, int32_t w, int32_t c_in, const float* weight, int32_t c_out,
+                      int32_t sigmoid, void* dx, float* dweight, float* dbias, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- loss heads (src/train_utils.py) ----------------------------------------------------- */
+size_t unet_loss_workspace(int64_t elems);
+/* CombinedLoss.forward (train_utils.py:30-44): losses[0] = mean((recon-image)^2),
+ * losses[1] = focal(amap, mask) (train_utils.py:23-28; BCE log clamp -100, backward
+ * denominator clamp 1e-12 as ATen).  Also writes d losses[0]/d recon and d losses[1]/d amap. */
+int32_t unet_loss_mse_focal(const float* recon, const float* image, int64_t n_recon, const float* amap,
+                            const float* mask, int64_t n_amap, float alpha, float gamma, float* losses,
+                            float* d_recon, float* d_amap, void* workspace, size_t workspace_bytes,
+                            void* stream);
+/* SSIMLoss (train_utils.py:67-104): 11-tap separable Gaussian (sigma 1.5), zero pad 5, NCHW fp32
+ * planes.  loss[0] = 1 - mean(ssim_map); d_img1/d_img2 (may be NULL) get d loss / d img. */
+size_t unet_ssim_workspace(int32_t planes, int32_t h, int32_t w);
+int32_t unet_ssim_loss(const float* img1, const float* img2, int32_t planes, int32_t h, int32_t w,
+                       int32_t window, float* loss, float* d_img1, float* d_img2, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---- optimiser (torch.optim.Adam of get_optimizer, src/train_utils.py:266) -------------- */
+/* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
+ * gradient pre-scale (1/world_size under data parallelism). step is 1-based. */
+int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       float grad_scale, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H_ */

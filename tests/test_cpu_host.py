@@ -1,0 +1,73 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every symbol of
+include/unet_hip.h, the drop-in modules keep the reference's state_dict layout and default init,
+and the product refuses to compute without a GPU (no fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from tiaozhanbei_unet_amd import _lib
+    return _lib.build()
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    from tiaozhanbei_unet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "unet_hip.h")).read()
+    declared = set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", header))
+    handle = ctypes.CDLL(libpath)
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in include/unet_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle.unet_abi_version.restype = ctypes.c_int32
+    assert handle.unet_abi_version() == 1
+
+
+def test_state_dict_layout_matches_reference():
+    import tiaozhanbei_unet_amd as P
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        pinned = json.load(f)
+    cases = {"unet_3_1": P.UNet(3, 1), "unet_3_4": P.UNet(3, 4), "unet_3_1_bilinear": P.UNet(3, 1, True),
+             "anomaly_unet_3": P.AnomalyUNet(3), "anomaly_unet_3_bilinear": P.AnomalyUNet(3, True)}
+    for name, m in cases.items():
+        got = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        assert got == pinned[name]["keys"], name
+        assert sum(p.numel() for p in m.parameters()) == pinned[name]["n_params"]
+        assert len(list(m.parameters())) == pinned[name]["n_param_tensors"]
+    m = P.AnomalyUNet(3)
+    assert m.n_channels == 3 and m.bilinear is False and P.UNet(3, 4).n_classes == 4
+
+
+def test_default_init_follows_torch_seed():
+    """Same registration order as the reference => same default init under torch.manual_seed."""
+    import tiaozhanbei_unet_amd as P
+    torch.manual_seed(7)
+    a = P.DoubleConv(3, 64)
+    torch.manual_seed(7)
+    w0 = torch.nn.Conv2d(3, 64, 3, padding=1, bias=False).weight
+    torch.nn.BatchNorm2d(64)
+    w1 = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).weight
+    assert torch.equal(a.double_conv[0].weight, w0) and torch.equal(a.double_conv[3].weight, w1)
+
+
+def test_no_cpu_fallback():
+    import tiaozhanbei_unet_amd as P
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.AnomalyUNet(3)(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.CombinedLoss()(torch.rand(1, 3, 4, 4), torch.rand(1, 1, 4, 4), torch.rand(1, 3, 4, 4), torch.zeros(1, 1, 4, 4))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "tiaozhanbei_unet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle", ""), f"{fn} mentions the oracle package"

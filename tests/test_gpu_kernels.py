@@ -1,0 +1,383 @@
+"""GPU parity tests, kernel level: each C-ABI entry point of libunet_hip.so against the CPU oracle /
+plain fp32 torch on the same seeded inputs.  fp32 kernels are held to tight bounds (the parity mode);
+bf16 kernels are compared on bf16-rounded inputs with a bound set by bf16 output rounding (2^-8)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import unet_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["fp32", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from tiaozhanbei_unet_amd import _lib, ops
+    return _lib, ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(name, shape, kind="normal"):
+    return W.make_input("k:" + name, shape, kind=kind)
+
+
+def q(t, dtype):
+    """value the kernel actually sees (bf16 rounding of inputs)"""
+    return t.to(dtype).float()
+
+
+def nhwc(t, dtype):
+    return t.to(dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def tol(dtype, ref, f32=2e-5, bf=1.2e-2):
+    return (f32 if dtype == torch.float32 else bf) * max(1.0, float(ref.abs().max()))
+
+
+def check(out, ref, dtype, what, f32=2e-5, bf=1.2e-2):
+    out, ref = out.detach().float().cpu(), ref.detach().float().cpu()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    err = float((out - ref).abs().max())
+    bound = tol(dtype, ref, f32, bf)
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e} (|ref|max {float(ref.abs().max()):.3e})"
+
+
+def views(L, items):
+    arr = L.View2()
+    for i, it in enumerate(items):
+        arr[i] = L.View(None, 0, 0, 0, 0, 0) if it is None else L.View(it[0].data_ptr(), it[0].shape[1],
+                                                                        it[0].shape[2], it[0].shape[3], it[1], it[2])
+    return arr
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ conv3x3 forward / dgrad / wgrad
+CONV_CASES = [  # n, cin, cout, h, w
+    (2, 64, 64, 16, 16), (1, 64, 128, 9, 21), (2, 128, 64, 8, 16), (1, 256, 128, 5, 3), (1, 64, 64, 40, 33)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3x3_fwd_dgrad_wgrad(hip, dtype, case):
+    L, ops = hip
+    n, ci, co, h, w = case
+    x = rnd(f"cx{case}", (n, ci, h, w))
+    wt = rnd(f"cw{case}", (co, ci, 3, 3)) * (1.0 / (3 * ci ** 0.5))
+    gy = rnd(f"cg{case}", (n, co, h, w))
+    xq, wq, gq = (q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), q(gy, dtype))
+    ref = F.conv2d(xq, wq, padding=1)
+    ref.backward(gq)
+    dt = ops._DT[dtype]
+    xd, gd = nhwc(x, dtype), nhwc(gy, dtype)
+    wd = wt.to(dev())
+    # forward
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wd, L.PACK_CONV_FWD, co, ci, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(xd, 0, 0), None]), p(wp), co, views(L, [(y, 0, 0), None]),
+                                 co, 0, L.K_CONV_FWD, st()), "conv fwd")
+    check(y, ref, dtype, "conv3x3 fwd")
+    # data gradient (same kernel, flipped weights)
+    dx = ops._nhwc_empty(n, ci, h, w, dtype, dev())
+    wpd = ops.pack_weight(wd, L.PACK_CONV_DGRAD, ci, co, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), ci, views(L, [(dx, 0, 0), None]),
+                                 ci, 0, L.K_CONV_DGRAD, st()), "conv dgrad")
+    check(dx, xq.grad, dtype, "conv3x3 dgrad")
+    # accumulate flag: dst += result
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), ci, views(L, [(dx, 0, 0), None]),
+                                 ci, 1, L.K_CONV_DGRAD, st()), "conv dgrad acc")
+    check(dx, 2 * xq.grad, dtype, "conv3x3 dgrad accumulate", bf=2.5e-2)
+    # weight gradient
+    dw = torch.empty(co, ci, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, views(L, [(xd, 0, 0), None]), p(gd), co, p(dw), ci, p(ws), need,
+                                       st()), "conv wgrad")
+    check(dw, wq.grad, dtype, "conv3x3 wgrad", f32=5e-5, bf=5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_conv3x3_image_layer_padded_channels(hip, dtype):
+    """3 image channels zero-padded to 64 by unet_nchw_to_nhwc; weight grad returns only the 3 real ones."""
+    L, ops = hip
+    n, ci, co, h, w = 2, 3, 64, 12, 20
+    x, wt, gy = rnd("ix", (n, ci, h, w)), rnd("iw", (co, ci, 3, 3)) * 0.2, rnd("ig", (n, co, h, w))
+    xq, wq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True)
+    ref = F.conv2d(xq, wq, padding=1)
+    ref.backward(q(gy, dtype))
+    xd = ops.PackInput.apply(x.to(dev()), dtype)
+    assert xd.shape == (n, 64, h, w)
+    back = torch.empty(n, ci, h, w, device=dev())
+    L.check(L.lib().unet_nhwc_to_nchw(p(xd), p(back), n, ci, h, w, 64, ops._DT[dtype], st()), "unpack")
+    check(back, q(x, dtype), dtype, "pack/unpack round trip", f32=0, bf=0)
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wt.to(dev()), L.PACK_CONV_FWD, co, 64, dtype)
+    L.check(L.lib().unet_conv3x3(ops._DT[dtype], n, h, w, views(L, [(xd, 0, 0), None]), p(wp), co,
+                                 views(L, [(y, 0, 0), None]), co, 0, 0, st()), "conv fwd")
+    check(y, ref, dtype, "image-layer conv")
+    gd = nhwc(gy, dtype)
+    dw = torch.empty(co, ci, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, 64, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(ops._DT[dtype], n, h, w, views(L, [(xd, 0, 0), None]), p(gd), co, p(dw), ci,
+                                       p(ws), need, st()), "wgrad")
+    check(dw, wq.grad, dtype, "image-layer wgrad", f32=5e-5, bf=5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_conv3x3_concat_and_centre_pad_views(hip, dtype):
+    """cat([x2, pad(x1)]) (model.py:57-65) expressed as two source views, and the matching
+    two-destination data gradient."""
+    L, ops = hip
+    n, c0, c1, co, h, w = 1, 64, 64, 64, 17, 19
+    h1, w1 = 16, 16
+    oy, ox = (h - h1) // 2, (w - w1) // 2
+    x2, x1 = rnd("vx2", (n, c0, h, w)), rnd("vx1", (n, c1, h1, w1))
+    wt = rnd("vw", (co, c0 + c1, 3, 3)) * 0.05
+    gy = rnd("vg", (n, co, h, w))
+    x2q, x1q = q(x2, dtype).requires_grad_(True), q(x1, dtype).requires_grad_(True)
+    wq = q(wt, dtype).requires_grad_(True)
+    x1p = F.pad(x1q, [ox, w - w1 - ox, oy, h - h1 - oy])
+    ref = F.conv2d(torch.cat([x2q, x1p], 1), wq, padding=1)
+    ref.backward(q(gy, dtype))
+    dt = ops._DT[dtype]
+    x2d, x1d, gd = nhwc(x2, dtype), nhwc(x1, dtype), nhwc(gy, dtype)
+    src = views(L, [(x2d, 0, 0), (x1d, oy, ox)])
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wt.to(dev()), L.PACK_CONV_FWD, co, c0 + c1, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, src, p(wp), co, views(L, [(y, 0, 0), None]), co, 0, 0, st()), "fwd")
+    check(y, ref, dtype, "two-source conv")
+    d2 = ops._nhwc_empty(n, c0, h, w, dtype, dev())
+    d1 = ops._nhwc_empty(n, c1, h1, w1, dtype, dev())
+    wpd = ops.pack_weight(wt.to(dev()), L.PACK_CONV_DGRAD, c0 + c1, co, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), c0 + c1,
+                                 views(L, [(d2, 0, 0), (d1, oy, ox)]), c0, 0, 1, st()), "dgrad")
+    check(d2, x2q.grad, dtype, "skip gradient")
+    check(d1, x1q.grad, dtype, "up-sampled gradient (cropped by the pad)")
+    dw = torch.empty(co, c0 + c1, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, src, p(gd), co, p(dw), c0 + c1, p(ws), need, st()), "wgrad")
+    check(dw, wq.grad, dtype, "two-source wgrad", f32=5e-5, bf=5e-3)
+
+
+# ------------------------------------------------------------------ transposed conv
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 128, 64, 8, 16), (1, 256, 128, 5, 3), (1, 128, 64, 9, 20)], ids=str)
+def test_convt2x2(hip, dtype, case):
+    L, ops = hip
+    n, ci, co, h, w = case
+    x, wt, b = rnd(f"tx{case}", (n, ci, h, w)), rnd(f"tw{case}", (ci, co, 2, 2)) * 0.1, rnd(f"tb{case}", (co,))
+    gy = rnd(f"tg{case}", (n, co, 2 * h, 2 * w))
+    xq, wq, bq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xq, wq, bq, stride=2)
+    check(O.conv_transpose2x2(xq, wq, bq), ref, torch.float32, "oracle convT restatement")
+    ref.backward(q(gy, dtype))
+    xd = nhwc(x, dtype).requires_grad_(True)
+    wd, bd = wt.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.ConvT2x2.apply(xd, wd, bd)
+    check(y, ref, dtype, "convT fwd")
+    y.backward(nhwc(gy, dtype))
+    check(xd.grad, xq.grad, dtype, "convT dgrad")
+    check(wd.grad, wq.grad, dtype, "convT wgrad", f32=5e-5, bf=5e-3)
+    check(bd.grad, bq.grad, dtype, "convT bias grad", f32=5e-5, bf=5e-3)
+
+
+# ------------------------------------------------------------------ BatchNorm + ReLU
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 64, 12, 20), (3, 128, 7, 5), (1, 64, 64, 64)], ids=str)
+def test_bn_relu_fwd_bwd(hip, dtype, case):
+    L, ops = hip
+    n, c, h, w = case
+    y = rnd(f"by{case}", (n, c, h, w)) * 1.7 + 0.3
+    ga, be = rnd(f"bg{case}", (c,), "uniform") + 0.5, rnd(f"bb{case}", (c,)) * 0.3
+    rm, rv = rnd(f"brm{case}", (c,)) * 0.1, rnd(f"brv{case}", (c,), "uniform") + 0.5
+    da = rnd(f"bd{case}", (n, c, h, w))
+    yq = q(y, dtype).requires_grad_(True)
+    gq, bq = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    state = {"b.weight": gq, "b.bias": bq, "b.running_mean": rm, "b.running_var": rv,
+             "b.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    new = {}
+    ref = torch.clamp_min(O.batch_norm(state, "b", yq, True, new), 0)
+    ref.backward(q(da, dtype))
+    dt, pixels = ops._DT[dtype], n * h * w
+    yd, dad = nhwc(y, dtype), nhwc(da, dtype)
+    gd, bd, rmd, rvd = ga.to(dev()), be.to(dev()), rm.to(dev()).clone(), rv.to(dev()).clone()
+    coef = torch.empty(4, c, device=dev())
+    need = L.lib().unet_bn_workspace(pixels, c)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_bn_train_stats(dt, p(yd), pixels, c, p(gd), p(bd), p(rmd), p(rvd), 0.1, 1e-5, p(coef[0]),
+                                        p(coef[1]), p(coef[2]), p(coef[3]), p(ws), need, st()), "bn stats")
+    a = torch.empty_like(yd)
+    L.check(L.lib().unet_bn_relu_apply(dt, p(yd), pixels, c, p(coef[2]), p(coef[3]), p(a), st()), "bn apply")
+    check(coef[0], yq.detach().mean((0, 2, 3)), torch.float32, "batch mean", f32=1e-5)
+    check(rmd, new["b.running_mean"], torch.float32, "running_mean", f32=1e-5)
+    check(rvd, new["b.running_var"], torch.float32, "running_var (unbiased)", f32=1e-5)
+    check(a, ref, dtype, "bn+relu fwd", f32=1e-5)
+    dy = torch.empty_like(yd)
+    dgb = torch.empty(2, c, device=dev())
+    L.check(L.lib().unet_bn_relu_bwd(dt, p(dad), p(yd), pixels, c, p(gd), p(coef[0]), p(coef[1]), p(coef[2]),
+                                     p(coef[3]), p(dgb[0]), p(dgb[1]), p(dy), p(ws), need, st()), "bn bwd")
+    check(dgb[0], gq.grad, torch.float32, "dgamma", f32=2e-5)
+    check(dgb[1], bq.grad, torch.float32, "dbeta", f32=2e-5)
+    check(dy, yq.grad, dtype, "bn+relu dgrad", f32=2e-5)
+    # eval coefficients
+    L.check(L.lib().unet_bn_eval_coeffs(c, p(gd), p(bd), p(rmd), p(rvd), 1e-5, p(coef[2]), p(coef[3]), st()), "eval")
+    L.check(L.lib().unet_bn_relu_apply(dt, p(yd), pixels, c, p(coef[2]), p(coef[3]), p(a), st()), "bn apply")
+    st2 = dict(state); st2.update(new)
+    check(a, torch.clamp_min(O.batch_norm(st2, "b", yq.detach(), False), 0), dtype, "bn eval", f32=1e-5)
+
+
+# ------------------------------------------------------------------ max-pool / bilinear
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 64, 13, 10), (1, 128, 8, 8), (1, 64, 5, 7)], ids=str)
+def test_maxpool(hip, dtype, case):
+    L, ops = hip
+    n, c, h, w = case
+    x = rnd(f"px{case}", (n, c, h, w))
+    x[:, :, 0:2, 0:2] = 1.0                       # tie: the gradient must go to the FIRST maximum
+    x[:, :, 2, 2], x[:, :, 2, 3], x[:, :, 3, 2], x[:, :, 3, 3] = 1.0, 2.0, 2.0, 1.0
+    xq = q(x, dtype).requires_grad_(True)
+    ref = F.max_pool2d(xq, 2)
+    gy = rnd(f"pg{case}", tuple(ref.shape))
+    ref.backward(q(gy, dtype))
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = ops.MaxPool2.apply(xd)
+    check(y, ref, dtype, "maxpool fwd", f32=0, bf=0)
+    y.backward(nhwc(gy, dtype))
+    check(xd.grad, xq.grad, dtype, "maxpool bwd (first-max ties, floor)", f32=0, bf=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(1, 64, 8, 8), (2, 64, 5, 3), (1, 128, 1, 4)], ids=str)
+def test_bilinear2x(hip, dtype, case):
+    L, ops = hip
+    n, c, h, w = case
+    x = rnd(f"ux{case}", (n, c, h, w))
+    xq = q(x, dtype).requires_grad_(True)
+    ref = F.interpolate(xq, scale_factor=2, mode="bilinear", align_corners=True)
+    check(O.upsample_bilinear2x(xq), ref, torch.float32, "oracle bilinear restatement", f32=1e-5)
+    gy = rnd(f"ug{case}", tuple(ref.shape))
+    ref.backward(q(gy, dtype))
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = ops.Bilinear2x.apply(xd)
+    check(y, ref, dtype, "bilinear fwd", f32=1e-5)
+    y.backward(nhwc(gy, dtype))
+    check(xd.grad, xq.grad, dtype, "bilinear bwd", f32=1e-5, bf=2e-2)
+
+
+# ------------------------------------------------------------------ 1x1 head
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("co", [1, 3, 4])
+@pytest.mark.parametrize("sigmoid", [False, True])
+def test_head(hip, dtype, co, sigmoid):
+    L, ops = hip
+    g = load_golden(f"block_outconv_64_{co}")
+    state = W.make_state(W.block_spec("outconv", 64, co), 0)
+    x = W.make_input(f"outc_{co}:x", (2, 64, 9, 11))
+    gy = W.make_input(f"outc_{co}:gy", (2, co, 9, 11))
+    xq = q(x, dtype).requires_grad_(True)
+    wq, bq = state["conv.weight"].clone().requires_grad_(True), state["conv.bias"].clone().requires_grad_(True)
+    ref = F.conv2d(xq, wq, bq)
+    if sigmoid:
+        ref = torch.sigmoid(ref)
+    ref.backward(gy)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    wd, bd = state["conv.weight"].to(dev()).requires_grad_(True), state["conv.bias"].to(dev()).requires_grad_(True)
+    out = ops.Head.apply(xd, wd, bd, sigmoid)
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    check(out, ref, torch.float32, "head fwd", f32=1e-5)
+    if dtype == torch.float32:
+        check(out, g["prob"] if sigmoid else g["logits"], torch.float32, "head fwd vs reference golden", f32=1e-5)
+        if not sigmoid:
+            assert torch.equal(out.argmax(1).to(torch.uint8).cpu(), g["argmax"]), "argmax mask indices differ"
+    out.backward(gy.to(dev()))
+    check(xd.grad, xq.grad, dtype, "head dx", f32=1e-5)
+    check(wd.grad, wq.grad, torch.float32, "head dW", f32=2e-5)
+    check(bd.grad, bq.grad, torch.float32, "head db", f32=2e-5)
+
+
+# ------------------------------------------------------------------ losses vs the reference's goldens
+LOSS_TAGS = [f"loss_combined_{t}_{rw}_{sw}" for t in ("binary", "over255", "zeros")
+             for rw, sw in ((1.0, 1.0), (0.3, 2.5))]
+
+
+@pytest.mark.parametrize("tag", LOSS_TAGS)
+def test_combined_loss_golden(hip, tag):
+    from tiaozhanbei_unet_amd import CombinedLoss
+    g = load_golden(tag)
+    rw, sw = map(float, tag.split("_")[-2:])
+    shape = (2, 3, 12, 10)
+    recon = W.make_input("loss:recon", shape, kind="uniform").to(dev()).requires_grad_(True)
+    image = W.make_input("loss:image", shape).to(dev())
+    amap = W.make_input("loss:amap", (2, 1, 12, 10), kind="uniform")
+    amap.view(-1)[:6] = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-7, 0.5, 1e-45])
+    amap = amap.to(dev()).requires_grad_(True)
+    d = CombinedLoss(recon_weight=rw, seg_weight=sw)(recon, amap, image, g["mask"].to(dev()))
+    assert set(d) == {"total_loss", "recon_loss", "seg_loss"} and d["total_loss"].dim() == 0
+    for k, gk in (("total_loss", "total"), ("recon_loss", "recon"), ("seg_loss", "seg")):
+        assert abs(float(d[k]) - float(g[gk])) <= 2e-6 + 2e-6 * abs(float(g[gk])), (k, float(d[k]), float(g[gk]))
+    d["total_loss"].backward()
+    err = (recon.grad.cpu() - g["d_recon"]).abs().max()
+    assert float(err) < 1e-8 + 1e-5 * float(g["d_recon"].abs().max())
+    ga, gr = amap.grad.cpu(), g["d_amap"]
+    assert bool(torch.isfinite(ga).all())
+    rel = ((ga - gr).abs() / (gr.abs() + 1e-7)).max()
+    assert float(rel) < 2e-3, f"focal gradient rel err {float(rel):.3e}"
+
+
+@pytest.mark.parametrize("c,hw", [(3, (40, 36)), (1, (20, 50)), (3, (64, 64))])
+def test_ssim_golden(hip, c, hw):
+    from tiaozhanbei_unet_amd import SSIMLoss
+    g = load_golden(f"ssim_c{c}_{hw[0]}x{hw[1]}")
+    a = W.make_input(f"ssim:a{c}", (2, c) + hw, kind="uniform").to(dev()).requires_grad_(True)
+    b = W.make_input(f"ssim:b{c}", (2, c) + hw).to(dev()).requires_grad_(True)
+    v = SSIMLoss()(a, b)
+    assert abs(float(v) - float(g["value"])) < 5e-6
+    v.backward()
+    for got, want, nm in ((a.grad, g["d_img1"], "d_img1"), (b.grad, g["d_img2"], "d_img2")):
+        err = float((got.cpu() - want).abs().max())
+        assert err < 1e-7 + 2e-4 * float(want.abs().max()), f"{nm}: {err:.3e}"
+    assert abs(float(SSIMLoss()(a.detach(), a.detach()))) < 5e-6
+
+
+# ------------------------------------------------------------------ fused Adam
+def test_adam_matches_torch(hip):
+    L, ops = hip
+    n = 4 * 1000
+    p0, g1, g2 = rnd("ap", (n,)), rnd("ag1", (n,)), rnd("ag2", (n,))
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-4)
+    pd = p0.to(dev()).clone()
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step, g in enumerate((g1, g2), 1):
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step_(pd, g.to(dev()), m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-4)
+    check(pd, ref.detach(), torch.float32, "adam", f32=1e-6)
+    one = torch.ones(4, device=dev())
+    ops.adam_step_(one, torch.zeros(4, device=dev()), torch.zeros(4, device=dev()), torch.zeros(4, device=dev()),
+                   1, 1e-3, 0.9, 0.999, 1e-8, 1e-4)
+    assert abs(float(one[0]) - 0.99900007) < 1e-6      # L2-coupled decay
+
+
+def test_cpu_tensors_are_refused(hip):
+    from tiaozhanbei_unet_amd import DoubleConv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DoubleConv(64, 64)(torch.zeros(1, 64, 8, 8))

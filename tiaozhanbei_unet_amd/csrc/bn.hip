@@ -1,0 +1,324 @@
+// BatchNorm2d (+ReLU) statistics, apply and backward for NHWC tensors on gfx950.
+// (nn.BatchNorm2d / nn.ReLU at /root/reference/src/model.py:15-16,18-19; semantics pinned in
+//  biased variance for normalisation, unbiased for the running estimate.)
+//
+// All kernels are HBM-bound streaming passes with 16-byte vector accesses.  Per-channel reductions are
+// two-stage and ordered (block partials -> fixed-order finalize in fp64), so results are bitwise
+// reproducible -- no float atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PARTS = 1024;
+
+// MODE 0: sum y, sum y^2       MODE 1: sum dz, sum dz*yhat (dz = da*[fma(y,scale,shift) > 0])     MODE 2: sum x
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y, const T* __restrict__ da,
+                                                        long long pixels, int C, int rows_per_block,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ istd,
+                                                        float* __restrict__ part) {
+  constexpr int PIECE = ET<T>::PIECE;        // channels per thread
+  constexpr int TPR = 64 / PIECE;            // threads per 64-channel row slice
+  constexpr int RPI = 256 / TPR;             // rows per iteration
+  __shared__ float red[2][RPI][64 + 1];
+  const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
+  const int c0 = blockIdx.x * 64 + tc * PIECE;
+  const long long r_begin = (long long)blockIdx.y * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > pixels) r_end = pixels;
+
+  float s0[PIECE], s1[PIECE], sc[PIECE], sh[PIECE], mu[PIECE], is[PIECE];
+#pragma unroll
+  for (int j = 0; j < PIECE; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = istd[c0 + j]; }
+  }
+  for (long long r = r_begin + tr; r < r_end; r += RPI) {
+    float v[PIECE];
+    Vec<T>::load(y + r * C + c0, v);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) { s0[j] += v[j]; s1[j] = fmaf(v[j], v[j], s1[j]); }
+    } else if (MODE == 1) {
+      float g[PIECE];
+      Vec<T>::load(da + r * C + c0, g);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const float z = fmaf(v[j], sc[j], sh[j]);
+        const float dz = z > 0.f ? g[j] : 0.f;
+        s0[j] += dz;
+        s1[j] = fmaf(dz, (v[j] - mu[j]) * is[j], s1[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) s0[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PIECE; ++j) { red[0][tr][tc * PIECE + j] = s0[j]; red[1][tr][tc * PIECE + j] = s1[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int q = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPI; ++i) s += red[q][i][c];
+    part[((size_t)blockIdx.y * 2 + q) * C + blockIdx.x * 64 + c] = s;
+  }
+}
+
+// ordered fp64 sum of the block partials; 4 row-lanes per channel
+__device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][4][64],
+                                 double& a, double& b) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = rl; k < nparts; k += 4) {
+    s0 += (double)part[((size_t)k * 2 + 0) * C + c];
+    s1 += (double)part[((size_t)k * 2 + 1) * C + c];
+  }
+  red[0][rl][c & 63] = s0;
+  red[1][rl][c & 63] = s1;
+  __syncthreads();
+  a = (red[0][0][c & 63] + red[0][1][c & 63]) + (red[0][2][c & 63] + red[0][3][c & 63]);
+  b = (red[1][0][c & 63] + red[1][1][c & 63]) + (red[1][2][c & 63] + red[1][3][c & 63]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(
+    const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* __restrict__ save_mean, float* __restrict__ save_istd, float* __restrict__ scale,
+    float* __restrict__ shift) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s, ss;
+  sum_parts(part, nparts, C, c, rl, red, s, ss);
+  if (rl != 0) return;
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float istd = (float)(1.0 / sqrt(var + (double)eps));
+  const float m = (float)mean;
+  save_mean[c] = m;
+  save_istd[c] = istd;
+  const float sc = gamma[c] * istd;
+  scale[c] = sc;
+  shift[c] = fmaf(-m, sc, beta[c]);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s, ss;
+  sum_parts(part, nparts, C, c, rl, red, s, ss);
+  if (rl != 0) return;
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)ss;
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                              float* __restrict__ out) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s, ss;
+  sum_parts(part, nparts, C, c, rl, red, s, ss);
+  if (rl == 0) out[c] = (float)s;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float istd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  const float sc = gamma[c] * istd;
+  scale[c] = sc;
+  shift[c] = fmaf(-rm[c], sc, beta[c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, long long pieces, int C,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ a) {
+  constexpr int PIECE = ET<T>::PIECE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pieces;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * PIECE) % C);
+    float v[PIECE];
+    Vec<T>::load(y + i * PIECE, v);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) v[j] = fmaxf(fmaf(v[j], scale[c0 + j], shift[c0 + j]), 0.f);
+    Vec<T>::store(a + i * PIECE, v);
+  }
+}
+
+// dy = gamma*istd * (dz - dbeta/M - yhat*dgamma/M)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
+    const T* __restrict__ da, const T* __restrict__ y, long long pieces, int C, float inv_count,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ istd,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ dgamma,
+    const float* __restrict__ dbeta, T* __restrict__ dy) {
+  constexpr int PIECE = ET<T>::PIECE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pieces;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * PIECE) % C);
+    float v[PIECE], g[PIECE];
+    Vec<T>::load(y + i * PIECE, v);
+    Vec<T>::load(da + i * PIECE, g);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) {
+      const int c = c0 + j;
+      const float z = fmaf(v[j], scale[c], shift[c]);
+      const float dz = z > 0.f ? g[j] : 0.f;
+      const float yhat = (v[j] - mean[c]) * istd[c];
+      g[j] = gamma[c] * istd[c] * (dz - dbeta[c] * inv_count - yhat * dgamma[c] * inv_count);
+    }
+    Vec<T>::store(dy + i * PIECE, g);
+  }
+}
+
+struct RedPlan { int nparts, rows_per_block; };
+RedPlan red_plan(long long pixels, int C) {
+  long long want = 2048 / (C / 64);
+  if (want < 1) want = 1;
+  if (want > MAX_PARTS) want = MAX_PARTS;
+  long long rpb = cdiv64(pixels, want);
+  rpb = cdiv64(rpb, 32) * 32;
+  RedPlan p;
+  p.rows_per_block = (int)rpb;
+  p.nparts = (int)cdiv64(pixels, rpb);
+  return p;
+}
+
+template <typename T, int MODE>
+int32_t launch_reduce(const void* y, const void* da, long long pixels, int C, const float* scale,
+                      const float* shift, const float* mean, const float* istd, float* part, RedPlan pl,
+                      hipStream_t s) {
+  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), dim3(C / 64, pl.nparts), dim3(256), 0, s, (const T*)y,
+                     (const T*)da, pixels, C, pl.rows_per_block, scale, shift, mean, istd, part);
+  return unet_check_launch("colreduce_kernel");
+}
+
+inline int ew_blocks(long long pieces) { return (int)std::min<long long>(cdiv64(pieces, 256), 256 * 16); }
+
+}  // namespace
+
+extern "C" size_t unet_bn_workspace(int64_t pixels, int32_t c) {
+  (void)pixels;
+  return (size_t)MAX_PARTS * 2 * (size_t)c * sizeof(float);
+}
+
+int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, float* out, float* ws,
+                             size_t ws_bytes, hipStream_t s) {
+  UNET_REQUIRE(C % 64 == 0, UNET_ERR_UNSUPPORTED, "colsum: channels %d not a multiple of 64", C);
+  RedPlan pl = red_plan(pixels, C);
+  const size_t per = (size_t)2 * C * sizeof(float);
+  if ((size_t)pl.nparts * per > ws_bytes) {
+    const long long fit = (long long)(ws_bytes / per);
+    UNET_REQUIRE(fit >= 1, UNET_ERR_WORKSPACE, "colsum: workspace %zu too small", ws_bytes);
+    pl.rows_per_block = (int)(cdiv64(cdiv64(pixels, fit), 32) * 32);
+    pl.nparts = (int)cdiv64(pixels, pl.rows_per_block);
+  }
+  int32_t rc = dtype == UNET_BF16
+                   ? launch_reduce<bf16_t, 2>(x, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, ws, pl, s)
+                   : launch_reduce<float, 2>(x, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, ws, pl, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 64), dim3(256), 0, s, ws, pl.nparts, C, out);
+  return unet_check_launch("colsum_finalize_kernel");
+}
+
+extern "C" int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pixels, int32_t c,
+                                       const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, float momentum, float eps, float* save_mean,
+                                       float* save_istd, float* scale, float* shift, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(y && gamma && beta && save_mean && save_istd && scale && shift && workspace, UNET_ERR_BAD_ARG,
+               "unet_bn_train_stats: null pointer");
+  UNET_REQUIRE(pixels > 0 && c > 0 && c % 64 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_train_stats: c=%d pixels=%lld",
+               c, (long long)pixels);
+  UNET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), UNET_ERR_BAD_ARG,
+               "unet_bn_train_stats: running_mean/var must both be given or both NULL");
+  const RedPlan pl = red_plan(pixels, c);
+  UNET_REQUIRE(workspace_bytes >= (size_t)pl.nparts * 2 * c * sizeof(float), UNET_ERR_WORKSPACE,
+               "unet_bn_train_stats: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  float* part = (float*)workspace;
+  int32_t rc = dtype == UNET_BF16
+                   ? launch_reduce<bf16_t, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s)
+                   : launch_reduce<float, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / 64), dim3(256), 0, s, part, pl.nparts, c, (double)pixels,
+                     gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale, shift);
+  return unet_check_launch("bn_finalize_train_kernel");
+}
+
+extern "C" int32_t unet_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta,
+                                       const float* running_mean, const float* running_var, float eps,
+                                       float* scale, float* shift, void* stream) {
+  UNET_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && c > 0, UNET_ERR_BAD_ARG,
+               "unet_bn_eval_coeffs: bad argument");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  return unet_check_launch("bn_eval_coeffs_kernel");
+}
+
+extern "C" int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixels, int32_t c,
+                                      const float* scale, const float* shift, void* a, void* stream) {
+  UNET_REQUIRE(y && scale && shift && a, UNET_ERR_BAD_ARG, "unet_bn_relu_apply: null pointer");
+  UNET_REQUIRE(pixels > 0 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_relu_apply: c=%d", c);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  if (dtype == UNET_BF16) {
+    const long long pieces = pixels * c / 8;
+    hipLaunchKernelGGL(bn_relu_apply_kernel<bf16_t>, dim3(ew_blocks(pieces)), dim3(256), 0, s, (const bf16_t*)y,
+                       pieces, c, scale, shift, (bf16_t*)a);
+  } else {
+    const long long pieces = pixels * c / 4;
+    hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3(ew_blocks(pieces)), dim3(256), 0, s, (const float*)y,
+                       pieces, c, scale, shift, (float*)a);
+  }
+  return unet_check_launch("bn_relu_apply_kernel");
+}
+
+extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                                    const float* gamma, const float* save_mean, const float* save_istd,
+                                    const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                    void* dy, void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(da && y && gamma && save_mean && save_istd && scale && shift && dgamma && dbeta && dy && workspace,
+               UNET_ERR_BAD_ARG, "unet_bn_relu_bwd: null pointer");
+  UNET_REQUIRE(pixels > 0 && c > 0 && c % 64 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_relu_bwd: c=%d", c);
+  const RedPlan pl = red_plan(pixels, c);
+  UNET_REQUIRE(workspace_bytes >= (size_t)pl.nparts * 2 * c * sizeof(float), UNET_ERR_WORKSPACE,
+               "unet_bn_relu_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  float* part = (float*)workspace;
+  int32_t rc = dtype == UNET_BF16
+                   ? launch_reduce<bf16_t, 1>(y, da, pixels, c, scale, shift, save_mean, save_istd, part, pl, s)
+                   : launch_reduce<float, 1>(y, da, pixels, c, scale, shift, save_mean, save_istd, part, pl, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c / 64), dim3(256), 0, s, part, pl.nparts, c, dgamma, dbeta);
+  rc = unet_check_launch("bn_finalize_bwd_kernel");
+  if (rc) return rc;
+  const float inv = (float)(1.0 / (double)pixels);
+  if (dtype == UNET_BF16) {
+    const long long pieces = pixels * c / 8;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                       (const bf16_t*)da, (const bf16_t*)y, pieces, c, inv, gamma, save_mean, save_istd, scale,
+                       shift, dgamma, dbeta, (bf16_t*)dy);
+  } else {
+    const long long pieces = pixels * c / 4;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                       (const float*)da, (const float*)y, pieces, c, inv, gamma, save_mean, save_istd, scale,
+                       shift, dgamma, dbeta, (float*)dy);
+  }
+  return unet_check_launch("bn_relu_bwd_apply_kernel");
+}

@@ -1,0 +1,91 @@
+// Shared device/host helpers for libunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define WAVE 64
+
+// ---- host side status handling ---------------------------------------------------------
+void unet_set_error(const char* fmt, ...);
+int32_t unet_check_launch(const char* what);
+
+#define UNET_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      unet_set_error(__VA_ARGS__);     \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// ---- per-class event timing (prof.cpp) ---------------------------------------------------
+void unet_prof_begin(int kclass, hipStream_t s);
+void unet_prof_end(int kclass, double flops, hipStream_t s);
+struct ProfScope {
+  int k; double f; hipStream_t s;
+  ProfScope(int kclass, double flops, hipStream_t st) : k(kclass), f(flops), s(st) { unet_prof_begin(k, s); }
+  ~ProfScope() { unet_prof_end(k, f, s); }
+};
+
+// deterministic per-channel sum of x[pixels][C] (bn.hip); ws is scratch
+int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, float* out, float* ws,
+                              size_t ws_bytes, hipStream_t s);
+
+// ---- element traits ----------------------------------------------------------------------
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int ES = 4;          // bytes per element
+  static constexpr int PIECE = 4;       // elements per 16-byte piece
+  static constexpr int KGC = 8;         // channels per 32-byte k-group
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct ET<bf16_t> {
+  static constexpr int ES = 2;
+  static constexpr int PIECE = 8;
+  static constexpr int KGC = 16;
+  __device__ static inline float to_f(bf16_t v) { return (float)v; }
+  __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+// 16-byte vector load/store of PIECE elements, converted to/from fp32
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static inline void load(const float* p, float (&o)[4]) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  __device__ static inline void store(float* p, const float (&o)[4]) {
+    f32x4 v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static inline void load(const bf16_t* p, float (&o)[8]) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  __device__ static inline void store(bf16_t* p, const float (&o)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,372 @@
+// HBM-bound streaming kernels of the hot path (gfx950): layout changes, weight packing, max-pool,
+// bilinear x2, fused Adam.  16-byte vector accesses along the channel (fastest) axis, grid-stride loops.
+#include "common.h"
+
+namespace {
+
+inline int ew_blocks(long long items) { return (int)std::min<long long>(cdiv64(items, 256), 256 * 16); }
+
+// ------------------------------------------------------------------------------- layout
+// One thread per (pixel, 4-channel group): reads are coalesced along w per channel plane.
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H,
+                                    int W, int Cp) {
+  const long long hw = (long long)H * W;
+  const int groups = Cp / 4;
+  const long long total = (long long)N * hw * groups;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % hw;
+    const long long t = i / hw;
+    const int g = (int)(t % groups);
+    const long long n = t / groups;
+    T* o = dst + (n * hw + p) * Cp + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = g * 4 + j;
+      const float v = c < C ? src[(n * C + c) * hw + p] : 0.f;
+      o[j] = ET<T>::from_f(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int H,
+                                    int W, int Cp) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)N * C * hw;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % hw;
+    const long long t = i / hw;
+    const int c = (int)(t % C);
+    const long long n = t / C;
+    dst[i] = ET<T>::to_f(src[(n * hw + p) * Cp + c]);
+  }
+}
+
+// ------------------------------------------------------------------------------- weight packing
+// out index -> source parameter index; zero where the padded GEMM dims exceed the parameter's.
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int rows,
+                                   int K, int mode, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (mode == UNET_PACK_CONV_FWD) {            // out[tap][co][ci]  <- w[co][ci][tap]
+      const int ci = (int)(i % K);
+      long long t = i / K;
+      const int co = (int)(t % rows);
+      const int tap = (int)(t / rows);
+      if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
+    } else if (mode == UNET_PACK_CONV_DGRAD) {   // out[tap'][ci][co] <- w[co][ci][8 - tap']
+      const int co = (int)(i % K);
+      long long t = i / K;
+      const int ci = (int)(t % rows);
+      const int tap = (int)(t / rows);
+      if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
+    } else if (mode == UNET_PACK_CONVT_FWD) {    // out[z][co][ci]    <- w[ci][co][z]
+      const int ci = (int)(i % K);
+      long long t = i / K;
+      const int co = (int)(t % rows);
+      const int z = (int)(t / rows);
+      if (co < Co && ci < Ci) v = w[((long long)ci * Co + co) * 4 + z];
+    } else {                                     // out[ci][z][co]    <- w[ci][co][z]      (row length 4*K)
+      const int co = (int)(i % K);
+      long long t = i / K;
+      const int z = (int)(t % 4);
+      const int ci = (int)(t / 4);
+      if (co < Co && ci < Ci) v = w[((long long)ci * Co + co) * 4 + z];
+    }
+    out[i] = ET<T>::from_f(v);
+  }
+}
+
+// ------------------------------------------------------------------------------- max pool 2x2
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int OH = H / 2, OW = W / 2, G = C / PIECE;
+  const long long total = (long long)N * OH * OW * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long t = i / G;
+    const int ox = (int)(t % OW);  t /= OW;
+    const int oy = (int)(t % OH);
+    const long long n = t / OH;
+    const T* p = x + ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    float a[PIECE], b[PIECE], c[PIECE], d[PIECE];
+    Vec<T>::load(p, a);
+    Vec<T>::load(p + C, b);
+    Vec<T>::load(p + (long long)W * C, c);
+    Vec<T>::load(p + (long long)W * C + C, d);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) a[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+    Vec<T>::store(y + i * PIECE, a);
+  }
+}
+
+// gradient goes to the FIRST maximum in row-major window order; rows/cols dropped by floor get 0.
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                    int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int OH = H / 2, OW = W / 2, G = C / PIECE;
+  const int WH = (H + 1) / 2, WW = (W + 1) / 2;   // windows incl. the ragged edge
+  const long long total = (long long)N * WH * WW * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long t = i / G;
+    const int ox = (int)(t % WW);  t /= WW;
+    const int oy = (int)(t % WH);
+    const long long n = t / WH;
+    const long long base = ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    float z[PIECE];
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) z[j] = 0.f;
+    if (oy < OH && ox < OW) {
+      float a[PIECE], b[PIECE], c[PIECE], d[PIECE], gr[PIECE];
+      Vec<T>::load(x + base, a);
+      Vec<T>::load(x + base + C, b);
+      Vec<T>::load(x + base + (long long)W * C, c);
+      Vec<T>::load(x + base + (long long)W * C + C, d);
+      Vec<T>::load(dy + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), gr);
+      float ga[PIECE], gb[PIECE], gc[PIECE], gd[PIECE];
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const float m = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+        const bool fa = a[j] == m, fb = !fa && b[j] == m, fc = !fa && !fb && c[j] == m;
+        const bool fd = !fa && !fb && !fc;
+        ga[j] = fa ? gr[j] : 0.f; gb[j] = fb ? gr[j] : 0.f; gc[j] = fc ? gr[j] : 0.f; gd[j] = fd ? gr[j] : 0.f;
+      }
+      Vec<T>::store(dx + base, ga);
+      Vec<T>::store(dx + base + C, gb);
+      Vec<T>::store(dx + base + (long long)W * C, gc);
+      Vec<T>::store(dx + base + (long long)W * C + C, gd);
+    } else {
+      // ragged edge: whatever exists of this window was not pooled
+      const int y0 = 2 * oy, x0 = 2 * ox;
+      for (int dyy = 0; dyy < 2; ++dyy)
+        for (int dxx = 0; dxx < 2; ++dxx)
+          if (y0 + dyy < H && x0 + dxx < W)
+            Vec<T>::store(dx + base + ((long long)dyy * W + dxx) * C, z);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- bilinear x2 (align_corners)
+__device__ inline void bil_axis(int o, int n_in, int n_out, int& i0, int& i1, float& f) {
+  const float src = (n_out > 1) ? o * ((float)(n_in - 1) / (float)(n_out - 1)) : 0.f;
+  i0 = (int)floorf(src);
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  f = src - (float)i0;
+}
+
+template <typename T>
+__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int OH = 2 * H, OW = 2 * W, G = C / PIECE;
+  const long long total = (long long)N * OH * OW * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long t = i / G;
+    const int ox = (int)(t % OW);  t /= OW;
+    const int oy = (int)(t % OH);
+    const long long n = t / OH;
+    int y0, y1, x0, x1; float fy, fx;
+    bil_axis(oy, H, OH, y0, y1, fy);
+    bil_axis(ox, W, OW, x0, x1, fx);
+    float a[PIECE], b[PIECE], c[PIECE], d[PIECE];
+    const T* p = x + n * H * (long long)W * C + g * PIECE;
+    Vec<T>::load(p + ((long long)y0 * W + x0) * C, a);
+    Vec<T>::load(p + ((long long)y0 * W + x1) * C, b);
+    Vec<T>::load(p + ((long long)y1 * W + x0) * C, c);
+    Vec<T>::load(p + ((long long)y1 * W + x1) * C, d);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) {
+      const float top = a[j] * (1.f - fx) + b[j] * fx, bot = c[j] * (1.f - fx) + d[j] * fx;
+      a[j] = top * (1.f - fy) + bot * fy;
+    }
+    Vec<T>::store(y + i * PIECE, a);
+  }
+}
+
+// gather form of the adjoint: each input pixel sums the (<= 3x3) output pixels that read it.
+template <typename T>
+__global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int OH = 2 * H, OW = 2 * W, G = C / PIECE;
+  const long long total = (long long)N * H * W * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long t = i / G;
+    const int ix = (int)(t % W);  t /= W;
+    const int iy = (int)(t % H);
+    const long long n = t / H;
+    float acc[PIECE];
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) acc[j] = 0.f;
+    // output rows whose source coordinate lies in (iy-1, iy+1)
+    const int oy_lo = max(0, 2 * iy - 2), oy_hi = min(OH - 1, 2 * iy + 3);
+    const int ox_lo = max(0, 2 * ix - 2), ox_hi = min(OW - 1, 2 * ix + 3);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float fy;
+      bil_axis(oy, H, OH, y0, y1, fy);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - fy;
+      if (y1 == iy) wy += fy;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float fx;
+        bil_axis(ox, W, OW, x0, x1, fx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - fx;
+        if (x1 == ix) wx += fx;
+        if (wx == 0.f) continue;
+        float v[PIECE];
+        Vec<T>::load(dy + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), v);
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) acc[j] = fmaf(v[j], wy * wx, acc[j]);
+      }
+    }
+    Vec<T>::store(dx + i * PIECE, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------- Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n4, float lr, float b1, float b2, float eps,
+                            float wd, float gscale, float bc1, float bc2_sqrt) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = fmaf(wd, pp[j], gg[j] * gscale);
+      mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pp[j] -= (lr / bc1) * (mm[j] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t unet_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                                     int32_t c_pad, int32_t dtype, void* stream) {
+  UNET_REQUIRE(src && dst, UNET_ERR_BAD_ARG, "unet_nchw_to_nhwc: null pointer");
+  UNET_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c && c_pad % 4 == 0, UNET_ERR_BAD_ARG,
+               "unet_nchw_to_nhwc: bad dims (c=%d c_pad=%d)", c, c_pad);
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)n * h * w * (c_pad / 4);
+  ProfScope prof(UNET_K_PACK, 0.0, s);
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, src, (bf16_t*)dst, n, c, h, w, c_pad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, src, (float*)dst, n, c, h, w, c_pad);
+  return unet_check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int32_t unet_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                                     int32_t c_pad, int32_t dtype, void* stream) {
+  UNET_REQUIRE(src && dst, UNET_ERR_BAD_ARG, "unet_nhwc_to_nchw: null pointer");
+  UNET_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, UNET_ERR_BAD_ARG, "unet_nhwc_to_nchw: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)n * h * w * c;
+  ProfScope prof(UNET_K_PACK, 0.0, s);
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)src, dst, n, c, h, w, c_pad);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)src, dst, n, c, h, w, c_pad);
+  return unet_check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int32_t unet_pack_weight(const float* w, void* out, int32_t c_out, int32_t c_in, int32_t rows,
+                                    int32_t k, int32_t mode, int32_t dtype, void* stream) {
+  UNET_REQUIRE(w && out, UNET_ERR_BAD_ARG, "unet_pack_weight: null pointer");
+  UNET_REQUIRE(c_out > 0 && c_in > 0 && rows > 0 && k > 0 && mode >= 0 && mode <= 3, UNET_ERR_BAD_ARG,
+               "unet_pack_weight: bad dims/mode");
+  const int gemm_rows = (mode == UNET_PACK_CONV_FWD || mode == UNET_PACK_CONVT_FWD) ? c_out : c_in;
+  const int gemm_k = (mode == UNET_PACK_CONV_FWD || mode == UNET_PACK_CONVT_FWD) ? c_in : c_out;
+  UNET_REQUIRE(rows >= gemm_rows && k >= gemm_k, UNET_ERR_BAD_ARG, "unet_pack_weight: padded dims too small");
+  const int taps = (mode <= UNET_PACK_CONV_DGRAD) ? 9 : 4;
+  const long long total = (long long)taps * rows * k;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_PACK, 0.0, s);
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (bf16_t*)out, c_out, c_in, rows, k, mode, total);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (float*)out, c_out, c_in, rows, k, mode, total);
+  return unet_check_launch("pack_weight_kernel");
+}
+
+#define EW_DISPATCH(NAME, KERN, TOTAL, ...)                                                                 \
+  do {                                                                                                        \
+    hipStream_t s = (hipStream_t)stream;                                                                      \
+    ProfScope prof(UNET_K_POOL, 0.0, s);                                                                      \
+    if (dtype == UNET_BF16) {                                                                                 \
+      typedef bf16_t T;                                                                                       \
+      const long long total = (TOTAL) / 8;                                                                    \
+      hipLaunchKernelGGL(KERN<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, __VA_ARGS__);                 \
+    } else {                                                                                                  \
+      typedef float T;                                                                                        \
+      const long long total = (TOTAL) / 4;                                                                    \
+      hipLaunchKernelGGL(KERN<float>, dim3(ew_blocks(total)), dim3(256), 0, s, __VA_ARGS__);                  \
+    }                                                                                                         \
+    return unet_check_launch(NAME);                                                                           \
+  } while (0)
+
+extern "C" int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c,
+                                     void* y, void* stream) {
+  UNET_REQUIRE(x && y, UNET_ERR_BAD_ARG, "unet_maxpool2_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_maxpool2_fwd: dims");
+  EW_DISPATCH("maxpool2_fwd_kernel", maxpool2_fwd_kernel, (long long)n * (h / 2) * (w / 2) * c, (const T*)x, (T*)y, n, h, w, c);
+}
+
+extern "C" int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* dy, int32_t n, int32_t h,
+                                     int32_t w, int32_t c, void* dx, void* stream) {
+  UNET_REQUIRE(x && dy && dx, UNET_ERR_BAD_ARG, "unet_maxpool2_bwd: null pointer");
+  UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_maxpool2_bwd: dims");
+  EW_DISPATCH("maxpool2_bwd_kernel", maxpool2_bwd_kernel, (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * c,
+              (const T*)x, (const T*)dy, (T*)dx, n, h, w, c);
+}
+
+extern "C" int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,
+                                                int32_t c, void* y, void* stream) {
+  UNET_REQUIRE(x && y, UNET_ERR_BAD_ARG, "unet_upsample_bilinear2x_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_upsample_bilinear2x_fwd: dims");
+  EW_DISPATCH("bilinear2x_fwd_kernel", bilinear2x_fwd_kernel, (long long)n * 4 * h * w * c, (const T*)x, (T*)y, n, h, w, c);
+}
+
+extern "C" int32_t unet_upsample_bilinear2x_bwd(int32_t dtype, const void* dy, int32_t n, int32_t h, int32_t w,
+                                                int32_t c, void* dx, void* stream) {
+  UNET_REQUIRE(dy && dx, UNET_ERR_BAD_ARG, "unet_upsample_bilinear2x_bwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_upsample_bilinear2x_bwd: dims");
+  EW_DISPATCH("bilinear2x_bwd_kernel", bilinear2x_bwd_kernel, (long long)n * h * w * c, (const T*)dy, (T*)dx, n, h, w, c);
+}
+
+extern "C" int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float grad_scale, int32_t step, void* stream) {
+  UNET_REQUIRE(param && grad && exp_avg && exp_avg_sq, UNET_ERR_BAD_ARG, "unet_adam_step: null pointer");
+  UNET_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, UNET_ERR_BAD_ARG, "unet_adam_step: n=%lld (must be a multiple of 4), step=%d",
+               (long long)n, step);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_OTHER, 0.0, s);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
+                     (long long)(n / 4), lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1,
+                     (float)sqrt(bc2));
+  return unet_check_launch("adam_kernel");
+}

@@ -1,0 +1,228 @@
+// 1x1 output head (OutConv, /root/reference/src/model.py:72) fused with bias and the optional sigmoid
+// of AnomalyUNet.forward (src/model.py:201,208).  K = c_in (64), N = c_out (1..8): arithmetic intensity
+// ~1-3 FLOP/B, HBM-bound, so this is a VALU streaming kernel, not an MFMA one.
+//
+// TPP = c_in/PIECE lanes cooperate on one pixel (each loads 16 B of its channels), partial dot products
+// are combined with wave shuffles.  Output is written NCHW fp32 (what the loss heads and callers read).
+// Backward recomputes nothing: dlogit = dout * out * (1 - out); dx is written NHWC in the compute dtype,
+// dW/db are block partials summed in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXCO = 8;
+
+template <typename T, int TPP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long long pixels, long long hw,
+                                                       int Cin, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int CO, int sigm,
+                                                       float* __restrict__ out) {
+  constexpr int PIECE = ET<T>::PIECE;
+  __shared__ float sw[MAXCO * 128];   // host checks c_out <= 8, c_in <= 128
+  for (int i = threadIdx.x; i < CO * Cin; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int g = threadIdx.x % TPP;
+  const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
+  const long long nslots = (long long)gridDim.x * 256 / TPP;
+  // every lane of a wave runs the same number of iterations (shuffles need all lanes)
+  const long long iters = cdiv64(pixels, nslots);
+  for (long long it = 0; it < iters; ++it) {
+    const long long p = slot + it * nslots;
+    const bool ok = p < pixels;
+    float v[PIECE];
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) v[j] = 0.f;
+    if (ok) Vec<T>::load(x + p * Cin + g * PIECE, v);
+    float acc[MAXCO];
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+      acc[co] = 0.f;
+      if (co < CO) {
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) acc[co] = fmaf(v[j], sw[co * Cin + g * PIECE + j], acc[co]);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < TPP; m <<= 1)
+#pragma unroll
+      for (int co = 0; co < MAXCO; ++co) acc[co] += __shfl_xor(acc[co], m);
+    if (ok && g < CO) {
+      float r = 0.f;
+#pragma unroll
+      for (int co = 0; co < MAXCO; ++co) if (co == g) r = acc[co];
+      r += b[g];
+      if (sigm) r = 1.f / (1.f + expf(-r));
+      const long long n = p / hw, q = p - n * hw;
+      out[(n * CO + g) * hw + q] = r;
+    }
+  }
+}
+
+template <typename T, int TPP>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ out,
+                                                       const float* __restrict__ dout, long long pixels,
+                                                       long long hw, int Cin, const float* __restrict__ w, int CO,
+                                                       int sigm, T* __restrict__ dx, float* __restrict__ part) {
+  constexpr int PIECE = ET<T>::PIECE;
+  __shared__ float sw[MAXCO * 128];
+  __shared__ float red[4][MAXCO * 129];
+  for (int i = threadIdx.x; i < CO * Cin; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int g = threadIdx.x % TPP;
+  const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
+  const long long nslots = (long long)gridDim.x * 256 / TPP;
+  const long long iters = cdiv64(pixels, nslots);
+  float dwacc[MAXCO][PIECE], dbacc[MAXCO];
+#pragma unroll
+  for (int co = 0; co < MAXCO; ++co) {
+    dbacc[co] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) dwacc[co][j] = 0.f;
+  }
+  for (long long it = 0; it < iters; ++it) {
+    const long long p = slot + it * nslots;
+    if (p >= pixels) continue;
+    const long long n = p / hw, q = p - n * hw;
+    float v[PIECE], d[PIECE];
+    Vec<T>::load(x + p * Cin + g * PIECE, v);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+      if (co < CO) {
+        float dl = dout[(n * CO + co) * hw + q];
+        if (sigm) { const float o = out[(n * CO + co) * hw + q]; dl *= o * (1.f - o); }
+        if (g == 0) dbacc[co] += dl;
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) {
+          d[j] = fmaf(dl, sw[co * Cin + g * PIECE + j], d[j]);
+          dwacc[co][j] = fmaf(dl, v[j], dwacc[co][j]);
+        }
+      }
+    }
+    Vec<T>::store(dx + p * Cin + g * PIECE, d);
+  }
+  // lanes with equal g (stride TPP) hold partials of the same channels: combine across the wave
+#pragma unroll
+  for (int m = TPP; m < 64; m <<= 1) {
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+      dbacc[co] += __shfl_xor(dbacc[co], m);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) dwacc[co][j] += __shfl_xor(dwacc[co][j], m);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stride = Cin + 1;
+  if (lane < TPP) {
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+      if (co < CO) {
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) red[wave][co * stride + lane * PIECE + j] = dwacc[co][j];
+        if (lane == 0) red[wave][co * stride + Cin] = dbacc[co];
+      }
+    }
+  }
+  __syncthreads();
+  // part[block][co][Cin+1]  (last column = bias gradient)
+  for (int i = threadIdx.x; i < CO * stride; i += 256)
+    part[(size_t)blockIdx.x * CO * stride + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int CO, int Cin,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+  const int stride = Cin + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CO * stride) return;
+  double s = 0.0;
+  for (int k = 0; k < nblocks; ++k) s += (double)part[(size_t)k * CO * stride + i];
+  const int co = i / stride, c = i % stride;
+  if (c < Cin) dw[co * Cin + c] = (float)s;
+  else db[co] = (float)s;
+}
+
+inline int head_blocks(long long pixels, int tpp) {
+  const long long per_block = 256 / tpp;
+  long long b = cdiv64(pixels, per_block * 8);   // ~8 pixels per slot
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename T>
+int tpp_of(int c_in) { return c_in / ET<T>::PIECE; }
+
+}  // namespace
+
+#define HEAD_TPP_SWITCH(T, tpp, CALL)                      \
+  switch (tpp) {                                           \
+    case 4: { constexpr int TPP = 4; CALL; } break;        \
+    case 8: { constexpr int TPP = 8; CALL; } break;        \
+    case 16: { constexpr int TPP = 16; CALL; } break;      \
+    case 32: { constexpr int TPP = 32; CALL; } break;      \
+    default:                                               \
+      unet_set_error("head: c_in %d unsupported", c_in);   \
+      return UNET_ERR_UNSUPPORTED;                         \
+  }
+
+extern "C" int32_t unet_head_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c_in,
+                                 const float* weight, const float* bias, int32_t c_out, int32_t sigmoid,
+                                 float* out, void* stream) {
+  UNET_REQUIRE(x && weight && bias && out, UNET_ERR_BAD_ARG, "unet_head_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_head_fwd: bad dims");
+  UNET_REQUIRE(c_out >= 1 && c_out <= MAXCO && c_in <= 128 && (c_in == 32 || c_in == 64 || c_in == 128), UNET_ERR_UNSUPPORTED,
+               "unet_head_fwd: %d -> %d channels unsupported (c_out <= 8, c_in in {32,64,128})", c_in, c_out);
+  UNET_REQUIRE(c_out <= c_in / (dtype == UNET_BF16 ? 8 : 4), UNET_ERR_UNSUPPORTED, "unet_head_fwd: c_out %d too wide for c_in %d", c_out, c_in);
+  hipStream_t s = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w, hw = (long long)h * w;
+  ProfScope prof(UNET_K_HEAD, 2.0 * pixels * c_in * c_out, s);
+  if (dtype == UNET_BF16) {
+    const int tpp = tpp_of<bf16_t>(c_in);
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_fwd_kernel<bf16_t, TPP>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
+                    (const bf16_t*)x, pixels, hw, c_in, weight, bias, c_out, sigmoid, out));
+  } else {
+    const int tpp = tpp_of<float>(c_in);
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_fwd_kernel<float, TPP>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
+                    (const float*)x, pixels, hw, c_in, weight, bias, c_out, sigmoid, out));
+  }
+  return unet_check_launch("head_fwd_kernel");
+}
+
+extern "C" size_t unet_head_bwd_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
+  (void)n; (void)h; (void)w;
+  return (size_t)2048 * c_out * (c_in + 1) * sizeof(float);
+}
+
+extern "C" int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out, const float* dout, int32_t n,
+                                 int32_t h, int32_t w, int32_t c_in, const float* weight, int32_t c_out,
+                                 int32_t sigmoid, void* dx, float* dweight, float* dbias, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(x && dout && weight && dx && dweight && dbias && workspace && (out || !sigmoid), UNET_ERR_BAD_ARG,
+               "unet_head_bwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_head_bwd: bad dims");
+  UNET_REQUIRE(c_out >= 1 && c_out <= MAXCO && c_in <= 128 && (c_in == 32 || c_in == 64 || c_in == 128), UNET_ERR_UNSUPPORTED,
+               "unet_head_bwd: %d -> %d channels unsupported", c_in, c_out);
+  UNET_REQUIRE(workspace_bytes >= unet_head_bwd_workspace(n, h, w, c_in, c_out), UNET_ERR_WORKSPACE,
+               "unet_head_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w, hw = (long long)h * w;
+  ProfScope prof(UNET_K_HEAD, 4.0 * pixels * c_in * c_out, s);
+  int nb = 0;
+  if (dtype == UNET_BF16) {
+    const int tpp = tpp_of<bf16_t>(c_in);
+    nb = head_blocks(pixels, tpp);
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP>), dim3(nb), dim3(256), 0, s,
+                    (const bf16_t*)x, out, dout, pixels, hw, c_in, weight, c_out, sigmoid, (bf16_t*)dx, (float*)workspace));
+  } else {
+    const int tpp = tpp_of<float>(c_in);
+    nb = head_blocks(pixels, tpp);
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_bwd_kernel<float, TPP>), dim3(nb), dim3(256), 0, s,
+                    (const float*)x, out, dout, pixels, hw, c_in, weight, c_out, sigmoid, (float*)dx, (float*)workspace));
+  }
+  int32_t rc = unet_check_launch("head_bwd_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(c_out * (c_in + 1), 128)), dim3(128), 0, s,
+                     (const float*)workspace, nb, c_out, c_in, dweight, dbias);
+  return unet_check_launch("head_bwd_finalize_kernel");
+}

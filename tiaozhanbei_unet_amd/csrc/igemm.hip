@@ -1,0 +1,379 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (CDNA4).
+//
+// One kernel template serves four operators of the hot path:
+//   conv3x3 forward      (nn.Conv2d 3x3 p1, /root/reference/src/model.py:14,17)      TAPS=9
+//   conv3x3 data grad    (same kernel, flipped/transposed packed weights)              TAPS=9
+//   convT2x2 forward     (nn.ConvTranspose2d k2 s2, src/model.py:51): 4 one-tap GEMMs
+//                        whose epilogue scatters to (2i+k, 2j+l) (pixel shuffle)       TAPS=1, omul=2
+//   convT2x2 data grad   one-tap GEMM whose K dimension gathers the 4 sub-positions    TAPS=1, gtaps=4
+//
+// GEMM view: D[co][pixel] = sum_k W[co][k] * X[pixel][k], k = (tap, ci).
+//   MFMA "A" operand = weights (rows = output channel), "B" operand = pixels, so every lane
+//   ends up owning ONE pixel and 4-channel runs of it -> 8/16-byte NHWC stores, no LDS transpose.
+// Tiling: block = 8x16 output pixels x BN output channels, 4 waves (64 lanes each),
+//   wave tile 64 co x (64|32) px out of 32x32 MFMA tiles; fp32 accumulate.
+// Staging: per Cin-chunk the (8+2)x(16+2) halo'd input patch is staged ONCE in LDS and reused
+//   by all 9 taps (tap = constant LDS offset); per tap a BN x chunk weight slab is staged into
+//   a 2-deep LDS ring, its global loads issued one tap ahead (register staged, T14-style).
+//   LDS rows are padded by 16 B so ds_read_b128 fragments are bank-conflict free.
+// The skip concat (src/model.py:65) and centre pad (src/model.py:57-61) are two source views:
+//   a chunk reads from src[0] or src[1]; out-of-view pixels read as zero.
+#include "common.h"
+
+namespace {
+
+struct DView { const char* p; int C, H, W, oy, ox; };
+struct DViewW { char* p; int C, H, W, oy, ox; };
+
+struct IgemmParams {
+  DView src[2];
+  DViewW dst[2];
+  int N, H, W;      // GEMM pixel grid (the logical frame)
+  int Ctot;         // input channels per (gather) tap = src[0].C + src[1].C
+  int Cout;         // GEMM rows
+  int wK;           // weight row length in elements
+  const char* w;
+  const float* bias;
+  int dst_split;
+  int accumulate;
+  int imul, gtaps;  // input position = frame*imul + gather tap (convT dgrad: 2, 4)
+  int omul, nZ;     // output position = frame*omul + z tap     (convT fwd:   2, 4)
+  int tilesX, tilesY, nCo;
+};
+
+constexpr int TH = 8, TW = 16, NPIX = TH * TW;
+
+template <typename T, int TAPS, int BN, int KG>
+struct Cfg {
+  static constexpr int R = (TAPS == 9) ? 3 : 1;
+  static constexpr int HH = TH + R - 1, HW = TW + R - 1;
+  static constexpr int CHB = KG * 32;              // chunk bytes per pixel / weight row
+  static constexpr int PSTR = CHB + 16;            // padded LDS row stride
+  static constexpr int PPP = CHB / 16;             // 16-byte pieces per row
+  static constexpr int A_BUFS = (TAPS == 1) ? 2 : 1;
+  static constexpr int A_BYTES = HH * HW * PSTR;
+  static constexpr int B_BYTES = BN * PSTR;
+  static constexpr int LDS = A_BUFS * A_BYTES + 2 * B_BYTES;
+  static constexpr int CK = KG * ET<T>::KGC;       // channels per chunk
+  static constexpr int WCO = BN / 64, WPX = 4 / WCO, PXT = NPIX / (32 * WPX);
+  static constexpr int NAP = (HH * HW * PPP + 255) / 256;
+  static constexpr int NBP = (BN * PPP + 255) / 256;
+  static constexpr bool BN_PIECES_EXACT = (BN * PPP) % 256 == 0;
+};
+
+template <typename T, int TAPS, int BN, int KG>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
+  using C = Cfg<T, TAPS, BN, KG>;
+  using E = ET<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sA = smem;
+  char* const sB = smem + C::A_BUFS * C::A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave % C::WCO, wpx = wave / C::WCO;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  // ---- XCD-aware block decode: consecutive logical ids (same pixel tile, all co tiles) share an XCD
+  int logical;
+  {
+    const int total = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int cot = logical % P.nCo;
+  int t = logical / P.nCo;
+  const int z = t % P.nZ;  t /= P.nZ;
+  const int txi = t % P.tilesX;  t /= P.tilesX;
+  const int tyi = t % P.tilesY;
+  const int n = t / P.tilesY;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int co0 = cot * BN;
+
+  f32x16 acc[2][C::PXT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < C::PXT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- per-lane LDS fragment bases
+  int aoff[2];   // weight rows (MFMA A operand)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) aoff[ct] = (wco * 64 + ct * 32 + l31) * C::PSTR + hh * 16;
+  int boff[C::PXT];  // pixel rows (MFMA B operand)
+#pragma unroll
+  for (int pt = 0; pt < C::PXT; ++pt) {
+    const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
+    boff[pt] = ((m >> 4) * C::HW + (m & 15)) * C::PSTR + hh * 16;
+  }
+
+  const int cpt = P.Ctot / C::CK;          // chunks per gather tap
+  const int nchunks = P.gtaps * cpt;
+
+  u32x4 breg[C::NBP];
+  auto load_b = [&](int tap, int chunk) {
+#pragma unroll
+    for (int i = 0; i < C::NBP; ++i) {
+      const int id = tid + i * 256;
+      if (C::BN_PIECES_EXACT || id < BN * C::PPP) {
+        const int row = id / C::PPP, part = id % C::PPP;
+        const size_t e = ((size_t)((z * TAPS + tap) * P.Cout + co0 + row)) * P.wK + (size_t)chunk * C::CK;
+        breg[i] = *reinterpret_cast<const u32x4*>(P.w + e * E::ES + part * 16);
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::NBP; ++i) {
+      const int id = tid + i * 256;
+      if (C::BN_PIECES_EXACT || id < BN * C::PPP) {
+        const int row = id / C::PPP, part = id % C::PPP;
+        *reinterpret_cast<u32x4*>(sB + buf * C::B_BYTES + row * C::PSTR + part * 16) = breg[i];
+      }
+    }
+  };
+
+  auto stage_a = [&](int chunk, int abuf) {
+    const int g = chunk / cpt, cc = chunk - g * cpt;
+    int ch = cc * C::CK;
+    const DView S = (ch < P.src[0].C) ? P.src[0] : P.src[1];
+    if (ch >= P.src[0].C) ch -= P.src[0].C;
+    const int gk = g >> 1, gl = g & 1;
+    constexpr int PADP = (TAPS == 9) ? 1 : 0;
+    u32x4 areg[C::NAP];
+#pragma unroll
+    for (int i = 0; i < C::NAP; ++i) {
+      const int id = tid + i * 256;
+      areg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (id < C::HH * C::HW * C::PPP) {
+        const int pix = id / C::PPP, part = id % C::PPP;
+        const int hy = pix / C::HW, hx = pix - hy * C::HW;
+        const int y = (ty0 + hy - PADP) * P.imul + gk - S.oy;
+        const int x = (tx0 + hx - PADP) * P.imul + gl - S.ox;
+        if (y >= 0 && y < S.H && x >= 0 && x < S.W) {
+          const size_t e = ((size_t)(n * S.H + y) * S.W + x) * S.C + ch;
+          areg[i] = *reinterpret_cast<const u32x4*>(S.p + e * E::ES + part * 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NAP; ++i) {
+      const int id = tid + i * 256;
+      if (id < C::HH * C::HW * C::PPP) {
+        const int pix = id / C::PPP, part = id % C::PPP;
+        *reinterpret_cast<u32x4*>(sA + abuf * C::A_BYTES + pix * C::PSTR + part * 16) = areg[i];
+      }
+    }
+  };
+
+  auto compute = [&](int tap, int abuf, int bbuf) {
+    const int toff = ((tap / C::R) * C::HW + (tap % C::R)) * C::PSTR;
+    const char* pa = sB + bbuf * C::B_BYTES;
+    const char* pb = sA + abuf * C::A_BYTES + toff;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 fa[2], fb[C::PXT];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fa[ct] = *reinterpret_cast<const bf16x8*>(pa + aoff[ct] + kg * 32);
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt) fb[pt] = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + kg * 32);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < C::PXT; ++pt)
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ct], fb[pt], acc[ct][pt], 0, 0, 0);
+      } else {
+        f32x4 fa[2], fb[C::PXT];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fa[ct] = *reinterpret_cast<const f32x4*>(pa + aoff[ct] + kg * 32);
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt) fb[pt] = *reinterpret_cast<const f32x4*>(pb + boff[pt] + kg * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < C::PXT; ++pt)
+              acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ct][j], fb[pt][j], acc[ct][pt], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop
+  load_b(0, 0);
+  int bbuf = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int abuf = (C::A_BUFS == 2) ? (c & 1) : 0;
+    if (C::A_BUFS == 1) __syncthreads();   // all waves done with the previous chunk's patch
+    stage_a(c, abuf);
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      store_b(bbuf);
+      __syncthreads();
+      if (tap + 1 < TAPS) load_b(tap + 1, c);
+      else if (c + 1 < nchunks) load_b(0, c + 1);
+      compute(tap, abuf, bbuf);
+      bbuf ^= 1;
+    }
+  }
+
+  // ---- epilogue: lane owns pixel (l31) and channels 8g+4h..+3 of each 32-row tile
+  const int zk = z >> 1, zl = z & 1;
+#pragma unroll
+  for (int pt = 0; pt < C::PXT; ++pt) {
+    const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
+    const int fy = ty0 + (m >> 4), fx = tx0 + (m & 15);
+    if (fy >= P.H || fx >= P.W) continue;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int co = co0 + wco * 64 + ct * 32 + 8 * g + 4 * hh;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][4 * g + j];
+        if (P.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += P.bias[co + j];
+        }
+        const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
+        if (co >= P.dst_split) co -= P.dst_split;
+        const int y = fy * P.omul + zk - D.oy, x = fx * P.omul + zl - D.ox;
+        if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
+        T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
+        if constexpr (sizeof(T) == 2) {
+          if (P.accumulate) {
+            bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+          }
+          bf16x4 r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = (bf16_t)v[j];
+          *reinterpret_cast<bf16x4*>(o) = r;
+        } else {
+          if (P.accumulate) {
+            f32x4 old = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += old[j];
+          }
+          *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int TAPS, int BN, int KG>
+int32_t launch(const IgemmParams& P, int kclass, hipStream_t s) {
+  using C = Cfg<T, TAPS, BN, KG>;
+  auto kern = igemm_kernel<T, TAPS, BN, KG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo * P.nZ;
+  UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "igemm: grid of %lld blocks", blocks);
+  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * TAPS * P.gtaps * P.nZ;
+  ProfScope prof(kclass, flops, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
+  return unet_check_launch("igemm_kernel");
+}
+
+template <typename T, int TAPS>
+int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s) {
+  constexpr int CK4 = 4 * ET<T>::KGC;
+  UNET_REQUIRE(P.Cout % 64 == 0, UNET_ERR_UNSUPPORTED, "igemm: c_out %d is not a multiple of 64", P.Cout);
+  UNET_REQUIRE(P.Ctot % ET<T>::KGC == 0, UNET_ERR_UNSUPPORTED, "igemm: input channels %d not a multiple of %d",
+               P.Ctot, ET<T>::KGC);
+  const bool big = (P.Cout % 128 == 0);
+  const bool k4 = (P.Ctot % CK4 == 0) && (P.src[1].C == 0 || P.src[0].C % CK4 == 0);
+  if (!k4)
+    UNET_REQUIRE(P.src[1].C == 0 || P.src[0].C % ET<T>::KGC == 0, UNET_ERR_UNSUPPORTED,
+                 "igemm: concat split %d not chunk aligned", P.src[0].C);
+  P.nCo = P.Cout / (big ? 128 : 64);
+  P.tilesX = cdiv(P.W, TW);
+  P.tilesY = cdiv(P.H, TH);
+  if (big) return k4 ? launch<T, TAPS, 128, 4>(P, kclass, s) : launch<T, TAPS, 128, 1>(P, kclass, s);
+  return k4 ? launch<T, TAPS, 64, 4>(P, kclass, s) : launch<T, TAPS, 64, 1>(P, kclass, s);
+}
+
+inline DView in_view(const unet_view& v) { return DView{(const char*)v.ptr, v.c, v.h, v.w, v.off_y, v.off_x}; }
+inline DViewW out_view(const unet_view& v) { return DViewW{(char*)v.ptr, v.c, v.h, v.w, v.off_y, v.off_x}; }
+
+}  // namespace
+
+extern "C" int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                                const void* w_packed, int32_t c_out, const unet_view dst[2],
+                                int32_t dst_split, int32_t accumulate, int32_t kclass, void* stream) {
+  UNET_REQUIRE(src && dst && w_packed && src[0].ptr && dst[0].ptr, UNET_ERR_BAD_ARG, "unet_conv3x3: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0 && c_out > 0, UNET_ERR_BAD_ARG, "unet_conv3x3: bad dims");
+  UNET_REQUIRE(dst_split == c_out || dst[1].ptr, UNET_ERR_BAD_ARG, "unet_conv3x3: dst[1] missing");
+  UNET_REQUIRE(dst_split % 64 == 0 && dst_split > 0 && dst_split <= c_out, UNET_ERR_UNSUPPORTED,
+               "unet_conv3x3: dst_split %d", dst_split);
+  IgemmParams P{};
+  P.src[0] = in_view(src[0]);
+  P.src[1] = src[1].ptr ? in_view(src[1]) : DView{nullptr, 0, 0, 0, 0, 0};
+  P.dst[0] = out_view(dst[0]);
+  P.dst[1] = dst[1].ptr ? out_view(dst[1]) : DViewW{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = P.src[0].C + P.src[1].C;
+  P.Cout = c_out;
+  P.wK = P.Ctot;
+  P.w = (const char*)w_packed;
+  P.bias = nullptr;
+  P.dst_split = dst_split;
+  P.accumulate = accumulate;
+  P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
+  if (kclass < 0 || kclass >= UNET_K_COUNT) kclass = UNET_K_CONV_FWD;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UNET_BF16) return dispatch<bf16_t, 9>(P, kclass, s);
+  if (dtype == UNET_F32) return dispatch<float, 9>(P, kclass, s);
+  unet_set_error("unet_conv3x3: dtype %d", dtype);
+  return UNET_ERR_BAD_ARG;
+}
+
+extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x,
+                                     int32_t c_in, const void* w_packed, const float* bias, void* y,
+                                     int32_t c_out, void* stream) {
+  UNET_REQUIRE(x && w_packed && y, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: bad dims");
+  IgemmParams P{};
+  P.src[0] = DView{(const char*)x, c_in, h, w, 0, 0};
+  P.dst[0] = DViewW{(char*)y, c_out, 2 * h, 2 * w, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = c_in; P.Cout = c_out; P.wK = c_in;
+  P.w = (const char*)w_packed;
+  P.bias = bias;
+  P.dst_split = c_out;
+  P.imul = 1; P.gtaps = 1; P.omul = 2; P.nZ = 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UNET_BF16) return dispatch<bf16_t, 1>(P, UNET_K_CONVT_FWD, s);
+  if (dtype == UNET_F32) return dispatch<float, 1>(P, UNET_K_CONVT_FWD, s);
+  unet_set_error("unet_convt2x2_fwd: dtype %d", dtype);
+  return UNET_ERR_BAD_ARG;
+}
+
+extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy,
+                                       int32_t c_out, const void* w_packed, void* dx, int32_t c_in,
+                                       void* stream) {
+  UNET_REQUIRE(dy && w_packed && dx, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: bad dims");
+  IgemmParams P{};
+  P.src[0] = DView{(const char*)dy, c_out, 2 * h, 2 * w, 0, 0};
+  P.dst[0] = DViewW{(char*)dx, c_in, h, w, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = c_out; P.Cout = c_in; P.wK = 4 * c_out;
+  P.w = (const char*)w_packed;
+  P.bias = nullptr;
+  P.dst_split = c_in;
+  P.imul = 2; P.gtaps = 4; P.omul = 1; P.nZ = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UNET_BF16) return dispatch<bf16_t, 1>(P, UNET_K_CONVT_DGRAD, s);
+  if (dtype == UNET_F32) return dispatch<float, 1>(P, UNET_K_CONVT_DGRAD, s);
+  unet_set_error("unet_convt2x2_dgrad: dtype %d", dtype);
+  return UNET_ERR_BAD_ARG;
+}

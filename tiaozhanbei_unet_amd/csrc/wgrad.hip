@@ -1,0 +1,332 @@
+// Weight-gradient GEMMs on MFMA for gfx950: the reduction runs over PIXELS.
+//
+//   conv3x3 :  dW[co][ci][r][s]  = sum_{n,y,x} dY[n,y,x,co] * X[n,y+r-1,x+s-1,ci]     (TAPS=9, S=1, PAD=1)
+//   convT2x2:  dW[ci][co][k][l]  = sum_{n,i,j} X[n,i,j,ci]  * dY[n,2i+k,2j+l,co]      (TAPS=4, S=2, PAD=0)
+// (autograd of nn.Conv2d / nn.ConvTranspose2d, /root/reference/src/model.py:14,17,51, reached from
+//  total_loss.backward() at src/train_utils.py:132.)
+//
+// Both are "out[r][c][tap] = sum_p R[p][r] * Cn[p*S + tap - PAD][c]" with a row tensor R and a column
+// tensor Cn.  Block = 64 rows x 64 cols x all taps (each wave 32x32 x TAPS fp32 accumulators), looping
+// over a range of pixel tiles (split-K).  Per tile the R tile and the halo'd Cn patch are staged ONCE in
+// LDS and reused by every tap.  The MFMA K dimension is the pixel index, which is the SLOW axis of NHWC,
+// so bf16 fragments are fetched with ds_read_b64_tr_b16 (hardware transpose, gfx950); fp32 fragments are
+// plain ds_read_b32 (one pixel per lane-half).  Partial slabs go to a caller workspace and are summed in
+// a fixed order by reduce_kernel -> bitwise reproducible gradients.
+#include "common.h"
+
+namespace {
+
+struct WView { const char* p; int C, H, W, oy, ox; };
+
+struct WgradParams {
+  WView rt;        // row tensor, geometry = frame
+  WView ct[2];     // column tensor(s); channel tile below ct[0].C reads ct[0], else ct[1]
+  int N, H, W;     // frame (pixel grid of the row tensor)
+  int Crow, Ccol;  // GEMM rows / cols (multiples of 64)
+  float* partial;  // [split][TAPS][Crow][Ccol]
+  int split, tilesPerSplit, tilesX, tilesY, nR, nC;
+};
+
+template <typename T, int TAPS>
+struct WCfg {
+  static constexpr int S = (TAPS == 9) ? 1 : 2;
+  static constexpr int R = (TAPS == 9) ? 3 : 2;
+  static constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  static constexpr int TH = (TAPS == 9) ? 8 : 4, TW = 16;
+  static constexpr int NPIX = TH * TW;
+  static constexpr int HH = (TH - 1) * S + R, HW = (TW - 1) * S + R;
+  static constexpr int ROWB = 64 * ET<T>::ES;                       // 64 channels per tile row
+  static constexpr int STR = (sizeof(T) == 2) ? ROWB + 64 : ROWB + 16;  // bf16: 192 B (tr-read conflict free)
+  static constexpr int PPR = ROWB / 16;
+  static constexpr int R_BYTES = NPIX * STR;
+  static constexpr int C_BYTES = HH * HW * STR;
+  static constexpr int LDS = R_BYTES + C_BYTES;
+  static constexpr int NRP = (NPIX * PPR + 255) / 256;
+  static constexpr int NCP = (HH * HW * PPR + 255) / 256;
+};
+
+__device__ inline bf16x8 tr_frag(const char* base, int off0, int off1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void wgrad_kernel(const WgradParams P) {
+  using C = WCfg<T, TAPS>;
+  using E = ET<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sR = smem;
+  char* const sC = smem + C::R_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int b = blockIdx.x;
+  const int ctile = b % P.nC;  b /= P.nC;
+  const int rtile = b % P.nR;
+  const int sp = b / P.nR;
+
+  // column source for this channel tile
+  int cch = ctile * 64;
+  const WView CS = (cch < P.ct[0].C) ? P.ct[0] : P.ct[1];
+  if (cch >= P.ct[0].C) cch -= P.ct[0].C;
+  const int rch = rtile * 64;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- per-lane fragment addressing
+  // bf16 (ds_read_b64_tr_b16): group g = lane>>4 covers channel block 16*(g&1) and k base 8*(g>>1);
+  // lane i=lane&15 supplies the address of pixel row q=i>>2, channels 4*(i&3)..+3 and receives channel i.
+  // fp32: lane reads pixel (2*step + hh), channel l31.
+  int r_lane, c_lane, kq;
+  if constexpr (sizeof(T) == 2) {
+    const int g = lane >> 4, i = lane & 15;
+    kq = 8 * (g >> 1) + (i >> 2);                       // pixel offset inside the 16-pixel k group (first read)
+    const int chb = (16 * (g & 1) + 4 * (i & 3)) * 2;   // channel byte offset inside the wave's 32 channels
+    r_lane = wr * 64 + chb;
+    c_lane = wc * 64 + chb;
+  } else {
+    kq = hh;
+    r_lane = (wr * 32 + l31) * 4;
+    c_lane = (wc * 32 + l31) * 4;
+  }
+
+  const int ntiles = P.N * P.tilesY * P.tilesX;
+  const int t_begin = sp * P.tilesPerSplit;
+  const int t_end = min(t_begin + P.tilesPerSplit, ntiles);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int t = tile;
+    const int txi = t % P.tilesX;  t /= P.tilesX;
+    const int tyi = t % P.tilesY;
+    const int n = t / P.tilesY;
+    const int ty0 = tyi * C::TH, tx0 = txi * C::TW;
+
+    // ---- stage (global -> regs -> LDS), zero outside the tensors
+    u32x4 rreg[C::NRP], creg[C::NCP];
+#pragma unroll
+    for (int i = 0; i < C::NRP; ++i) {
+      const int id = tid + i * 256;
+      rreg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (id < C::NPIX * C::PPR) {
+        const int pix = id / C::PPR, part = id % C::PPR;
+        const int y = ty0 + pix / C::TW, x = tx0 + pix % C::TW;
+        if (y < P.H && x < P.W) {
+          const size_t e = ((size_t)(n * P.rt.H + y) * P.rt.W + x) * P.rt.C + rch;
+          rreg[i] = *reinterpret_cast<const u32x4*>(P.rt.p + e * E::ES + part * 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NCP; ++i) {
+      const int id = tid + i * 256;
+      creg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (id < C::HH * C::HW * C::PPR) {
+        const int pix = id / C::PPR, part = id % C::PPR;
+        const int hy = pix / C::HW, hx = pix - hy * C::HW;
+        const int y = ty0 * C::S + hy - C::PAD - CS.oy, x = tx0 * C::S + hx - C::PAD - CS.ox;
+        if (y >= 0 && y < CS.H && x >= 0 && x < CS.W) {
+          const size_t e = ((size_t)(n * CS.H + y) * CS.W + x) * CS.C + cch;
+          creg[i] = *reinterpret_cast<const u32x4*>(CS.p + e * E::ES + part * 16);
+        }
+      }
+    }
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < C::NRP; ++i) {
+      const int id = tid + i * 256;
+      if (id < C::NPIX * C::PPR)
+        *reinterpret_cast<u32x4*>(sR + (id / C::PPR) * C::STR + (id % C::PPR) * 16) = rreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < C::NCP; ++i) {
+      const int id = tid + i * 256;
+      if (id < C::HH * C::HW * C::PPR)
+        *reinterpret_cast<u32x4*>(sC + (id / C::PPR) * C::STR + (id % C::PPR) * 16) = creg[i];
+    }
+    __syncthreads();
+
+    // ---- MFMA over the tile's pixels: one k group = one tile row of 16 pixels
+#pragma unroll 1
+    for (int ty = 0; ty < C::TH; ++ty) {
+      if constexpr (sizeof(T) == 2) {
+        const int rp = (ty * C::TW + kq) * C::STR + r_lane;
+        const bf16x8 fa = tr_frag(sR, rp, rp + 4 * C::STR);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int ky = tap / C::R, kx = tap % C::R;
+          const int cp = ((ty * C::S + ky) * C::HW + kq * C::S + kx) * C::STR + c_lane;
+          const bf16x8 fb = tr_frag(sC, cp, cp + 4 * C::S * C::STR);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const int px = 2 * st + kq;
+          const float fa = *reinterpret_cast<const float*>(sR + (ty * C::TW + px) * C::STR + r_lane);
+#pragma unroll
+          for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / C::R, kx = tap % C::R;
+            const float fb = *reinterpret_cast<const float*>(
+                sC + ((ty * C::S + ky) * C::HW + px * C::S + kx) * C::STR + c_lane);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tap], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial slab: D[row i][col j], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int col = ctile * 64 + wc * 32 + l31;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    float* o = P.partial + ((size_t)(sp * TAPS + tap) * P.Crow) * P.Ccol;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rtile * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      o[(size_t)row * P.Ccol + col] = acc[tap][r];
+    }
+  }
+}
+
+// out[r][c][tap] (fp32, r < rows_out, c < cols_out) = sum_s partial[s][tap][r][c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int split,
+                                    int taps, int Crow, int Ccol, int rows_out, int cols_out) {
+  const long long total = (long long)rows_out * cols_out * taps;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long long rc = i / taps;
+    const int c = (int)(rc % cols_out), r = (int)(rc / cols_out);
+    const size_t slab = (size_t)taps * Crow * Ccol;
+    const float* p = partial + ((size_t)tap * Crow + r) * Ccol + c;
+    float s = 0.f;
+    for (int k = 0; k < split; ++k) s += p[(size_t)k * slab];
+    out[i] = s;
+  }
+}
+
+struct Plan { int tilesX, tilesY, nR, nC, split, tilesPerSplit; size_t bytes; };
+
+template <int TAPS>
+Plan make_plan(int n, int h, int w, int crow, int ccol) {
+  Plan p;
+  constexpr int TH = (TAPS == 9) ? 8 : 4;
+  p.tilesX = cdiv(w, 16);
+  p.tilesY = cdiv(h, TH);
+  p.nR = crow / 64;
+  p.nC = ccol / 64;
+  const long long ntiles = (long long)n * p.tilesY * p.tilesX;
+  long long want = 1024 / ((long long)p.nR * p.nC);
+  if (want < 1) want = 1;
+  if (want > ntiles) want = ntiles;
+  p.tilesPerSplit = (int)cdiv64(ntiles, want);
+  p.split = (int)cdiv64(ntiles, p.tilesPerSplit);
+  p.bytes = (size_t)p.split * TAPS * crow * ccol * sizeof(float);
+  return p;
+}
+
+template <typename T, int TAPS>
+int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_out, int kclass, hipStream_t s) {
+  using C = WCfg<T, TAPS>;
+  auto kern = wgrad_kernel<T, TAPS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  P.tilesX = pl.tilesX; P.tilesY = pl.tilesY; P.nR = pl.nR; P.nC = pl.nC;
+  P.split = pl.split; P.tilesPerSplit = pl.tilesPerSplit;
+  const long long blocks = (long long)pl.split * pl.nR * pl.nC;
+  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
+  {
+    ProfScope prof(kclass, flops, s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
+    int32_t rc = unet_check_launch("wgrad_kernel");
+    if (rc) return rc;
+    const long long total = (long long)rows_out * cols_out * TAPS;
+    const int rb = (int)std::min<long long>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, P.partial, out, pl.split, TAPS, P.Crow,
+                       P.Ccol, rows_out, cols_out);
+  }
+  return unet_check_launch("wgrad_reduce_kernel");
+}
+
+inline int pad64(int c) { return (c + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" size_t unet_conv3x3_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
+  return make_plan<9>(n, h, w, pad64(c_out), pad64(c_in)).bytes;
+}
+
+extern "C" int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                                      const void* dy, int32_t c_out, float* dw, int32_t c_in_param,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(src && src[0].ptr && dy && dw && workspace, UNET_ERR_BAD_ARG, "unet_conv3x3_wgrad: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_conv3x3_wgrad: bad dims");
+  const int ctot = src[0].c + (src[1].ptr ? src[1].c : 0);
+  UNET_REQUIRE(c_out % 64 == 0, UNET_ERR_UNSUPPORTED, "unet_conv3x3_wgrad: c_out %d not a multiple of 64", c_out);
+  // the image layer (8/16 padded channels) reads a 64-channel column tile: the caller must have padded
+  // the tensor to 64 channels or given c % 64 == 0 views.
+  UNET_REQUIRE(ctot % 64 == 0 && (!src[1].ptr || src[0].c % 64 == 0), UNET_ERR_UNSUPPORTED,
+               "unet_conv3x3_wgrad: input channels %d(+%d) must be multiples of 64", src[0].c,
+               src[1].ptr ? src[1].c : 0);
+  UNET_REQUIRE(c_in_param <= ctot, UNET_ERR_BAD_ARG, "unet_conv3x3_wgrad: c_in_param %d > %d", c_in_param, ctot);
+  const Plan pl = make_plan<9>(n, h, w, c_out, ctot);
+  UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_conv3x3_wgrad: workspace %zu < %zu",
+               workspace_bytes, pl.bytes);
+  WgradParams P{};
+  P.rt = WView{(const char*)dy, c_out, h, w, 0, 0};
+  P.ct[0] = WView{(const char*)src[0].ptr, src[0].c, src[0].h, src[0].w, src[0].off_y, src[0].off_x};
+  P.ct[1] = src[1].ptr ? WView{(const char*)src[1].ptr, src[1].c, src[1].h, src[1].w, src[1].off_y, src[1].off_x}
+                       : WView{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Crow = c_out; P.Ccol = ctot;
+  P.partial = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UNET_BF16) return run<bf16_t, 9>(P, pl, dw, c_out, c_in_param, UNET_K_CONV_WGRAD, s);
+  if (dtype == UNET_F32) return run<float, 9>(P, pl, dw, c_out, c_in_param, UNET_K_CONV_WGRAD, s);
+  unet_set_error("unet_conv3x3_wgrad: dtype %d", dtype);
+  return UNET_ERR_BAD_ARG;
+}
+
+extern "C" size_t unet_convt2x2_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
+  return make_plan<4>(n, h, w, pad64(c_in), pad64(c_out)).bytes;
+}
+
+extern "C" int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x,
+                                       int32_t c_in, const void* dy, int32_t c_out, float* dw, float* db,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(x && dy && dw && db && workspace, UNET_ERR_BAD_ARG, "unet_convt2x2_wgrad: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_wgrad: bad dims");
+  UNET_REQUIRE(c_in % 64 == 0 && c_out % 64 == 0, UNET_ERR_UNSUPPORTED,
+               "unet_convt2x2_wgrad: channels %d -> %d must be multiples of 64", c_in, c_out);
+  const Plan pl = make_plan<4>(n, h, w, c_in, c_out);
+  UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_convt2x2_wgrad: workspace %zu < %zu",
+               workspace_bytes, pl.bytes);
+  WgradParams P{};
+  P.rt = WView{(const char*)x, c_in, h, w, 0, 0};
+  P.ct[0] = WView{(const char*)dy, c_out, 2 * h, 2 * w, 0, 0};
+  P.ct[1] = WView{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Crow = c_in; P.Ccol = c_out;
+  P.partial = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t rc;
+  if (dtype == UNET_BF16) rc = run<bf16_t, 4>(P, pl, dw, c_in, c_out, UNET_K_CONVT_WGRAD, s);
+  else if (dtype == UNET_F32) rc = run<float, 4>(P, pl, dw, c_in, c_out, UNET_K_CONVT_WGRAD, s);
+  else { unet_set_error("unet_convt2x2_wgrad: dtype %d", dtype); return UNET_ERR_BAD_ARG; }
+  if (rc) return rc;
+  // bias gradient: column sums of dy; the partial slabs above are consumed (stream order), reuse them
+  return unet_internal_colsum(dtype, dy, (int64_t)n * 4 * h * w, c_out, db, (float*)workspace, workspace_bytes, s);
+}

@@ -1,0 +1,214 @@
+"""U-Net model zoo of the reference, running on hand-written gfx950 kernels.
+
+Drop-in surface (same class names, constructor / forward signatures, attributes and
+``state_dict`` key layout as /root/reference/src/model.py): ``DoubleConv`` (:6-23),
+``Down`` (:26-37), ``Up`` (:40-66), ``OutConv`` (:69-75), ``UNet`` (:78-108),
+``AnomalyUNet`` (:156-210).
+
+The stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` children are kept
+ONLY as parameter holders -- same registration order, hence the same default
+initialisation under ``torch.manual_seed`` and the same checkpoint keys as the reference --
+their ``forward`` is never called.  All arithmetic goes through ``ops`` (libunet_hip.so).
+
+Extra, optional, keyword: ``precision`` in {"fp32", "bf16"} (default: the package default,
+fp32 = the parity mode; bf16 = the throughput mode with fp32 accumulation, fp32 BatchNorm
+statistics and fp32 master parameters).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}
+_default_precision = "fp32"
+
+
+def set_default_precision(precision: str) -> None:
+    global _default_precision
+    if precision not in _DTYPES:
+        raise ValueError(f"precision must be one of {sorted(_DTYPES)}")
+    _default_precision = precision
+
+
+def set_precision(module: nn.Module, precision: str) -> nn.Module:
+    """Switch every block of ``module`` to ``precision`` (parameters stay fp32)."""
+    if precision not in _DTYPES:
+        raise ValueError(f"precision must be one of {sorted(_DTYPES)}")
+    for m in module.modules():
+        if isinstance(m, _HipBlock):
+            m.precision = precision
+    return module
+
+
+class _HipBlock(nn.Module):
+    precision = None
+
+    @property
+    def compute_dtype(self) -> torch.dtype:
+        return _DTYPES[self.precision or _default_precision]
+
+
+def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool):
+    track = training or bn.running_mean is None
+    out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               track, bn.momentum if bn.momentum is not None else 0.1)
+    if training and bn.num_batches_tracked is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+    return out
+
+
+class DoubleConv(_HipBlock):
+    """(conv3x3 => BatchNorm => ReLU) * 2 on MFMA implicit-GEMM kernels."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, precision=None):
+        super().__init__()
+        mid_channels = mid_channels or out_channels
+        if mid_channels % 64 or out_channels % 64:
+            raise ValueError("the gfx950 kernels need output channel counts that are multiples of 64 "
+                             f"(got {mid_channels}, {out_channels})")
+        self.precision = precision
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x, x_up=None):
+        """``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
+        tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly."""
+        seq = self.double_conv
+        x = ops.to_operator_layout(x, self.compute_dtype)
+        if x_up is not None:
+            x_up = ops.to_operator_layout(x_up, self.compute_dtype)
+        a = _conv_bn_relu(seq[0], seq[1], x, x_up, self.training)
+        return _conv_bn_relu(seq[3], seq[4], a, None, self.training)
+
+
+class Down(_HipBlock):
+    """MaxPool2d(2) then DoubleConv."""
+
+    def __init__(self, in_channels, out_channels, precision=None):
+        super().__init__()
+        self.precision = precision
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels, precision=precision))
+
+    def forward(self, x):
+        x = ops.to_operator_layout(x, self.compute_dtype)
+        return self.maxpool_conv[1](ops.MaxPool2.apply(x))
+
+
+class Up(_HipBlock):
+    """Up-sample (transposed conv or bilinear), centre-pad to the skip, concat skip-first, DoubleConv."""
+
+    def __init__(self, in_channels, out_channels, bilinear=True, precision=None):
+        super().__init__()
+        self.precision = precision
+        self.bilinear = bool(bilinear)
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2, precision=precision)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels, precision=precision)
+
+    def forward(self, x1, x2):
+        dt = self.compute_dtype
+        x1 = ops.to_operator_layout(x1, dt)
+        x2 = ops.to_operator_layout(x2, dt)
+        if self.bilinear:
+            u = ops.Bilinear2x.apply(x1)
+        else:
+            u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
+        return self.conv(x2, u)
+
+
+class OutConv(_HipBlock):
+    """1x1 convolution with bias; returns NCHW fp32 logits."""
+
+    def __init__(self, in_channels, out_channels, precision=None):
+        super().__init__()
+        self.precision = precision
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x, sigmoid=False):
+        x = ops.to_operator_layout(x, self.compute_dtype)
+        return ops.Head.apply(x, self.conv.weight, self.conv.bias, sigmoid)
+
+
+def _encoder(m, x):
+    x1 = m.inc(x)
+    x2 = m.down1(x1)
+    x3 = m.down2(x2)
+    x4 = m.down3(x3)
+    x5 = m.down4(x4)
+    return x1, x2, x3, x4, x5
+
+
+class UNet(_HipBlock):
+    def __init__(self, n_channels=3, n_classes=1, bilinear=False, precision=None):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+        self.precision = precision
+        factor = 2 if bilinear else 1
+        self.inc = DoubleConv(n_channels, 64, precision=precision)
+        self.down1 = Down(64, 128, precision=precision)
+        self.down2 = Down(128, 256, precision=precision)
+        self.down3 = Down(256, 512, precision=precision)
+        self.down4 = Down(512, 1024 // factor, precision=precision)
+        self.up1 = Up(1024, 512 // factor, bilinear, precision=precision)
+        self.up2 = Up(512, 256 // factor, bilinear, precision=precision)
+        self.up3 = Up(256, 128 // factor, bilinear, precision=precision)
+        self.up4 = Up(128, 64, bilinear, precision=precision)
+        self.outc = OutConv(64, n_classes, precision=precision)
+
+    def forward(self, x):
+        x1, x2, x3, x4, x5 = _encoder(self, x)
+        y = self.up1(x5, x4)
+        y = self.up2(y, x3)
+        y = self.up3(y, x2)
+        y = self.up4(y, x1)
+        return self.outc(y)
+
+
+class AnomalyUNet(_HipBlock):
+    """Shared encoder + reconstruction decoder + anomaly-segmentation decoder; both heads sigmoid."""
+
+    def __init__(self, n_channels=3, bilinear=False, precision=None):
+        super().__init__()
+        self.n_channels = n_channels
+        self.bilinear = bilinear
+        self.precision = precision
+        factor = 2 if bilinear else 1
+        self.inc = DoubleConv(n_channels, 64, precision=precision)
+        self.down1 = Down(64, 128, precision=precision)
+        self.down2 = Down(128, 256, precision=precision)
+        self.down3 = Down(256, 512, precision=precision)
+        self.down4 = Down(512, 1024 // factor, precision=precision)
+        for branch, n_out in (("recon", n_channels), ("seg", 1)):
+            setattr(self, f"up1_{branch}", Up(1024, 512 // factor, bilinear, precision=precision))
+            setattr(self, f"up2_{branch}", Up(512, 256 // factor, bilinear, precision=precision))
+            setattr(self, f"up3_{branch}", Up(256, 128 // factor, bilinear, precision=precision))
+            setattr(self, f"up4_{branch}", Up(128, 64, bilinear, precision=precision))
+            setattr(self, f"outc_{branch}", OutConv(64, n_out, precision=precision))
+
+    def _decode(self, feats, branch):
+        x1, x2, x3, x4, x5 = feats
+        y = getattr(self, f"up1_{branch}")(x5, x4)
+        y = getattr(self, f"up2_{branch}")(y, x3)
+        y = getattr(self, f"up3_{branch}")(y, x2)
+        y = getattr(self, f"up4_{branch}")(y, x1)
+        return getattr(self, f"outc_{branch}")(y, sigmoid=True)
+
+    def forward(self, x):
+        feats = _encoder(self, x)
+        reconstruction = self._decode(feats, "recon")
+        anomaly_map = self._decode(feats, "seg")
+        return reconstruction, anomaly_map

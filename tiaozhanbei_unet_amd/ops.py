@@ -1,0 +1,431 @@
+"""autograd operators over the C-ABI of libunet_hip.so.
+
+PyTorch is plumbing here: it owns device memory (the caching allocator), the stream and
+the autograd tape; every FLOP of these operators runs in hand-written gfx950 HIP kernels
+reached through ``_lib`` (ctypes).  Tensors between operators are logical-NCHW torch
+tensors with ``channels_last`` strides (i.e. NHWC in memory) in the compute dtype
+(``torch.bfloat16`` or ``torch.float32``).  There is no fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.UNET_F32, torch.bfloat16: L.UNET_BF16}
+BN_EPS = 1e-5
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "tiaozhanbei_unet_amd runs only on an AMD GPU through libunet_hip.so; got a "
+                f"{t.device} tensor (there is deliberately no CPU fallback)")
+
+
+def _nhwc_empty(n, c, h, w, dtype, device):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def _is_nhwc(t: torch.Tensor) -> bool:
+    """Dense NHWC in memory (strides of size-1 dims are irrelevant)."""
+    n, c, h, w = t.shape
+    want = (h * w * c, 1, w * c, c)
+    return all(sz == 1 or st == wt for sz, st, wt in zip(t.shape, t.stride(), want))
+
+
+def _as_nhwc(t: torch.Tensor, dtype) -> torch.Tensor:
+    """Activation/gradient in the operators' layout.  (Only reached for tensors produced outside
+    these operators, e.g. a test's upstream gradient.)"""
+    if t.dtype == dtype and _is_nhwc(t):
+        return t
+    out = _nhwc_empty(*t.shape, dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch arena per device; stream-ordered reuse (one compute stream)."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _views(items) -> "L.View2":
+    arr = L.View2()
+    for i, it in enumerate(items):
+        if it is None:
+            arr[i] = L.View(None, 0, 0, 0, 0, 0)
+        else:
+            t, oy, ox = it
+            arr[i] = L.View(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], oy, ox)
+    return arr
+
+
+def _pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+# ----------------------------------------------------------------------------- layout
+class PackInput(torch.autograd.Function):
+    """NCHW fp32 image batch -> NHWC compute dtype, channels zero-padded to a multiple of 64
+    (the tensor entering ``self.inc`` at /root/reference/src/model.py:190)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_cuda(x)
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        cp = _pad64(c)
+        out = _nhwc_empty(n, cp, h, w, dtype, x.device)
+        L.check(L.lib().unet_nchw_to_nhwc(_ptr(x), _ptr(out), n, c, h, w, cp, _DT[dtype], _stream()),
+                "unet_nchw_to_nhwc")
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, cp, h, w = g.shape
+        g = _as_nhwc(g, g.dtype)
+        out = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=g.device)
+        L.check(L.lib().unet_nhwc_to_nchw(_ptr(g), _ptr(out), n, ctx.c, h, w, cp, _DT[g.dtype], _stream()),
+                "unet_nhwc_to_nchw")
+        return out, None
+
+
+def to_operator_layout(x: torch.Tensor, dtype) -> torch.Tensor:
+    """Accept what a caller of the reference modules would pass (NCHW fp32, any channel count) or an
+    activation already in operator layout."""
+    _require_cuda(x)
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
+    if x.dtype == dtype and _is_nhwc(x) and x.shape[1] % 64 == 0:
+        return x
+    if x.shape[1] % 64 == 0 and x.dtype == dtype:
+        return _ToNHWC.apply(x)
+    return PackInput.apply(x, dtype)
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _as_nhwc(x, x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def pack_weight(w: torch.Tensor, mode: int, rows: int, k: int, dtype) -> torch.Tensor:
+    taps = 9 if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD) else 4
+    out = torch.empty(taps * rows * k, dtype=dtype, device=w.device)
+    if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD):
+        co, ci = w.shape[0], w.shape[1]
+    else:
+        ci, co = w.shape[0], w.shape[1]
+    L.check(L.lib().unet_pack_weight(_ptr(w), _ptr(out), co, ci, rows, k, mode, _DT[dtype], _stream()),
+            "unet_pack_weight")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
+class ConvBnRelu(torch.autograd.Function):
+    """relu(batch_norm(conv3x3(cat([x0, x1])))) -- one third of DoubleConv
+    (/root/reference/src/model.py:14-16 / :17-19); ``x1`` (optional) is the up-sampled tensor
+    of Up.forward, centre-padded to x0's size (src/model.py:57-65) without materialising pad or cat."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum):
+        _require_cuda(x0, weight)
+        dtype = x0.dtype
+        dt = _DT[dtype]
+        n, c0, h, w = x0.shape
+        c1 = 0 if x1 is None else x1.shape[1]
+        oy = ox = 0
+        if x1 is not None:
+            dy_, dx_ = h - x1.shape[2], w - x1.shape[3]
+            if dy_ < 0 or dx_ < 0:
+                raise ValueError("Up: the skip tensor must be at least as large as the up-sampled one")
+            oy, ox = dy_ // 2, dx_ // 2
+        co, ci = weight.shape[0], weight.shape[1]
+        ctot = c0 + c1
+        if not (ci <= ctot < ci + 64):
+            raise ValueError(f"conv weight expects {ci} input channels, activations carry {ctot}")
+        lib, st, dev = L.lib(), _stream(), x0.device
+        wp = pack_weight(weight, L.PACK_CONV_FWD, co, ctot, dtype)
+        y = _nhwc_empty(n, co, h, w, dtype, dev)
+        src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
+        dst = _views([(y, 0, 0), None])
+        L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
+        pixels = n * h * w
+        coef = torch.empty((4, co), dtype=torch.float32, device=dev)   # mean, istd, scale, shift
+        if training:
+            ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
+            L.check(lib.unet_bn_train_stats(dt, _ptr(y), pixels, co, _ptr(gamma), _ptr(beta),
+                                            _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
+                                            _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]),
+                                            _ptr(ws), ws.numel(), st), "unet_bn_train_stats")
+        else:
+            L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                            BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
+        a = _nhwc_empty(n, co, h, w, dtype, dev)
+        L.check(lib.unet_bn_relu_apply(dt, _ptr(y), pixels, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(a), st),
+                "unet_bn_relu_apply")
+        ctx.save_for_backward(x0, x1, y, weight, gamma, coef)
+        ctx.geom = (oy, ox, training)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x0, x1, y, weight, gamma, coef = ctx.saved_tensors
+        oy, ox, training = ctx.geom
+        if not training:
+            raise RuntimeError("backward through BatchNorm in eval mode is not on the hot path (unsupported)")
+        dtype = x0.dtype
+        dt = _DT[dtype]
+        n, c0, h, w = x0.shape
+        co, ci = weight.shape[0], weight.shape[1]
+        ctot = c0 + (0 if x1 is None else x1.shape[1])
+        lib, st, dev = L.lib(), _stream(), x0.device
+        da = _as_nhwc(da, dtype)
+        pixels = n * h * w
+        dy = _nhwc_empty(n, co, h, w, dtype, dev)
+        dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
+        ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
+        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
+                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
+                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+        src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            need = lib.unet_conv3x3_wgrad_workspace(n, h, w, ctot, co)
+            ws = _workspace(need, dev)
+            L.check(lib.unet_conv3x3_wgrad(dt, n, h, w, src, _ptr(dy), co, _ptr(dw), ci, _ptr(ws), ws.numel(), st),
+                    "unet_conv3x3_wgrad")
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            wp = pack_weight(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
+            dx0 = _nhwc_empty(n, c0, h, w, dtype, dev)
+            if x1 is not None:
+                dx1 = _nhwc_empty(*x1.shape, dtype, dev)
+            dsrc = _views([(dy, 0, 0), None])
+            ddst = _views([(dx0, 0, 0), None if x1 is None else (dx1, oy, ox)])
+            L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 0, L.K_CONV_DGRAD, st),
+                    "unet_conv3x3(dgrad)")
+        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None
+
+
+# ----------------------------------------------------------------------------- max pool
+class MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2) (/root/reference/src/model.py:32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        n, c, h, w = x.shape
+        if h < 2 or w < 2:
+            raise ValueError("MaxPool2d(2) needs at least 2x2 pixels")
+        y = _nhwc_empty(n, c, h // 2, w // 2, x.dtype, x.device)
+        L.check(L.lib().unet_maxpool2_fwd(_DT[x.dtype], _ptr(x), n, h, w, c, _ptr(y), _stream()), "unet_maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = _as_nhwc(dy, x.dtype)
+        dx = _nhwc_empty(n, c, h, w, x.dtype, x.device)
+        L.check(L.lib().unet_maxpool2_bwd(_DT[x.dtype], _ptr(x), _ptr(dy), n, h, w, c, _ptr(dx), _stream()),
+                "unet_maxpool2_bwd")
+        return dx
+
+
+# ----------------------------------------------------------------------------- up-sampling
+class ConvT2x2(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cin//2, kernel_size=2, stride=2) (/root/reference/src/model.py:51)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_cuda(x, weight)
+        n, ci, h, w = x.shape
+        co = weight.shape[1]
+        dtype = x.dtype
+        wp = pack_weight(weight, L.PACK_CONVT_FWD, co, ci, dtype)
+        y = _nhwc_empty(n, co, 2 * h, 2 * w, dtype, x.device)
+        L.check(L.lib().unet_convt2x2_fwd(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(wp), _ptr(bias), _ptr(y), co,
+                                          _stream()), "unet_convt2x2_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        n, ci, h, w = x.shape
+        co = weight.shape[1]
+        dtype = x.dtype
+        lib, st, dev = L.lib(), _stream(), x.device
+        dy = _as_nhwc(dy, dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wp = pack_weight(weight, L.PACK_CONVT_DGRAD, ci, co, dtype)
+            dx = _nhwc_empty(n, ci, h, w, dtype, dev)
+            L.check(lib.unet_convt2x2_dgrad(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(dx), ci, st),
+                    "unet_convt2x2_dgrad")
+        dw = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty(co, dtype=torch.float32, device=dev)
+        ws = _workspace(lib.unet_convt2x2_wgrad_workspace(n, h, w, ci, co), dev)
+        L.check(lib.unet_convt2x2_wgrad(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(dy), co, _ptr(dw), _ptr(db),
+                                        _ptr(ws), ws.numel(), st), "unet_convt2x2_wgrad")
+        return dx, dw, db
+
+
+class Bilinear2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (/root/reference/src/model.py:48)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        n, c, h, w = x.shape
+        y = _nhwc_empty(n, c, 2 * h, 2 * w, x.dtype, x.device)
+        L.check(L.lib().unet_upsample_bilinear2x_fwd(_DT[x.dtype], _ptr(x), n, h, w, c, _ptr(y), _stream()),
+                "unet_upsample_bilinear2x_fwd")
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = _as_nhwc(dy, dy.dtype)
+        dx = _nhwc_empty(n, c, h, w, dy.dtype, dy.device)
+        L.check(L.lib().unet_upsample_bilinear2x_bwd(_DT[dy.dtype], _ptr(dy), n, h, w, c, _ptr(dx), _stream()),
+                "unet_upsample_bilinear2x_bwd")
+        return dx
+
+
+# ----------------------------------------------------------------------------- 1x1 head
+class Head(torch.autograd.Function):
+    """OutConv (1x1 conv + bias, /root/reference/src/model.py:72) with the optional sigmoid of
+    AnomalyUNet.forward (src/model.py:201,208).  Output: NCHW fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sigmoid):
+        _require_cuda(x, weight)
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        out = torch.empty((n, co, h, w), dtype=torch.float32, device=x.device)
+        L.check(L.lib().unet_head_fwd(_DT[x.dtype], _ptr(x), n, h, w, ci, _ptr(weight), _ptr(bias), co,
+                                      int(sigmoid), _ptr(out), _stream()), "unet_head_fwd")
+        ctx.save_for_backward(x, weight, out)
+        ctx.sigmoid = bool(sigmoid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        lib, dev = L.lib(), x.device
+        dout = dout.contiguous().float()
+        dx = _nhwc_empty(n, ci, h, w, x.dtype, dev)
+        dw = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty(co, dtype=torch.float32, device=dev)
+        ws = _workspace(lib.unet_head_bwd_workspace(n, h, w, ci, co), dev)
+        L.check(lib.unet_head_bwd(_DT[x.dtype], _ptr(x), _ptr(out), _ptr(dout), n, h, w, ci, _ptr(weight), co,
+                                  int(ctx.sigmoid), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                "unet_head_bwd")
+        return dx, dw, db, None
+
+
+# ----------------------------------------------------------------------------- losses
+class MseFocal(torch.autograd.Function):
+    """(MSE(recon, image), focal(amap, mask)) -- /root/reference/src/train_utils.py:23-35."""
+
+    @staticmethod
+    def forward(ctx, recon, amap, image, mask, alpha, gamma):
+        _require_cuda(recon, amap, image, mask)
+        recon, amap = recon.contiguous().float(), amap.contiguous().float()
+        image, mask = image.contiguous().float(), mask.contiguous().float()
+        if recon.shape != image.shape or amap.shape != mask.shape:
+            raise ValueError("CombinedLoss: prediction/target shapes differ")
+        lib, dev = L.lib(), recon.device
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        d_recon, d_amap = torch.empty_like(recon), torch.empty_like(amap)
+        ws = _workspace(lib.unet_loss_workspace(recon.numel()), dev)
+        L.check(lib.unet_loss_mse_focal(_ptr(recon), _ptr(image), recon.numel(), _ptr(amap), _ptr(mask),
+                                        amap.numel(), float(alpha), float(gamma), _ptr(losses), _ptr(d_recon),
+                                        _ptr(d_amap), _ptr(ws), ws.numel(), _stream()), "unet_loss_mse_focal")
+        ctx.save_for_backward(d_recon, d_amap)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_mse, g_focal):
+        d_recon, d_amap = ctx.saved_tensors
+        return d_recon * g_mse, d_amap * g_focal, None, None, None, None
+
+
+class Ssim(torch.autograd.Function):
+    """SSIMLoss.forward (/root/reference/src/train_utils.py:89-104), size_average=True."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, window_size):
+        _require_cuda(img1, img2)
+        img1, img2 = img1.contiguous().float(), img2.contiguous().float()
+        n, c, h, w = img1.shape
+        lib, dev = L.lib(), img1.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d1 = torch.empty_like(img1) if need else None
+        d2 = torch.empty_like(img2) if need else None
+        ws = _workspace(lib.unet_ssim_workspace(n * c, h, w), dev)
+        L.check(lib.unet_ssim_loss(_ptr(img1), _ptr(img2), n * c, h, w, int(window_size), _ptr(loss), _ptr(d1),
+                                   _ptr(d2), _ptr(ws), ws.numel(), _stream()), "unet_ssim_loss")
+        if need:
+            ctx.save_for_backward(d1, d2)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2 = ctx.saved_tensors
+        return d1 * g, d2 * g, None
+
+
+# ----------------------------------------------------------------------------- profiling / optimiser
+def prof_enable(on: bool) -> None:
+    L.check(L.lib().unet_prof_enable(int(on)), "unet_prof_enable")
+
+
+def prof_collect():
+    ms = (C.c_double * L.K_COUNT)()
+    launches = (C.c_int64 * L.K_COUNT)()
+    flops = (C.c_double * L.K_COUNT)()
+    L.check(L.lib().unet_prof_collect(ms, launches, flops), "unet_prof_collect")
+    return {L.KCLASS_NAMES[i]: {"ms": ms[i], "launches": launches[i], "flops": flops[i]}
+            for i in range(L.K_COUNT)}
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    """In-place fused Adam over flat fp32 arenas (torch.optim.Adam semantics, train_utils.py:266)."""
+    _require_cuda(param, grad, exp_avg, exp_avg_sq)
+    L.check(L.lib().unet_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                   lr, beta1, beta2, eps, weight_decay, grad_scale, int(step), _stream()),
+            "unet_adam_step")

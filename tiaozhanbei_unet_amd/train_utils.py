@@ -1,0 +1,150 @@
+"""Loss heads and the train / validate loops of the reference, on the HIP path.
+
+Same call surface as /root/reference/src/train_utils.py: ``CombinedLoss`` (:10-44),
+``SSIMLoss`` (:47-104), ``train_epoch`` (:107-152), ``validate_epoch`` (:155-260),
+``get_optimizer`` (:263-272), ``get_scheduler`` (:275-284).  The loss arithmetic runs in
+libunet_hip.so (ops.MseFocal / ops.Ssim); the loops are host plumbing with the reference's
+return-dict keys.  Two deliberate differences, both value-preserving: the three per-step
+``.item()`` host syncs (:137-139) become device-side running sums read once per epoch, and
+``--use_ssim`` (dead in the reference, src/train.py:191-194) is honoured when a caller opts in
+through ``CombinedLoss(recon_criterion=SSIMLoss())``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import AverageMeter, calculate_metrics, compute_anomaly_score
+
+
+class SSIMLoss(nn.Module):
+    """1 - mean SSIM with an 11x11 Gaussian window (sigma 1.5), zero padded."""
+
+    def __init__(self, window_size=11, size_average=True):
+        super().__init__()
+        if not size_average:
+            raise NotImplementedError("size_average=False is not on the hot path")
+        self.window_size = window_size
+        self.size_average = size_average
+
+    def forward(self, img1, img2):
+        return ops.Ssim.apply(img1, img2, self.window_size)
+
+
+class CombinedLoss(nn.Module):
+    """recon_weight * MSE(recon, image) + seg_weight * focal(anomaly_map, mask)."""
+
+    def __init__(self, recon_weight=1.0, seg_weight=1.0, focal_alpha=0.25, focal_gamma=2.0,
+                 recon_criterion=None):
+        super().__init__()
+        self.recon_weight = recon_weight
+        self.seg_weight = seg_weight
+        self.focal_alpha = focal_alpha
+        self.focal_gamma = focal_gamma
+        self.recon_criterion = recon_criterion      # None = MSE (what the reference always uses)
+
+    def focal_loss(self, pred, target):
+        zero = pred.new_zeros((1, 1, 1, 1))
+        return ops.MseFocal.apply(zero, pred, zero, target, self.focal_alpha, self.focal_gamma)[1]
+
+    def forward(self, reconstruction, anomaly_map, original_image, true_mask):
+        recon_loss, seg_loss = ops.MseFocal.apply(reconstruction, anomaly_map, original_image, true_mask,
+                                                  self.focal_alpha, self.focal_gamma)
+        if self.recon_criterion is not None:
+            recon_loss = self.recon_criterion(reconstruction, original_image)
+        total = self.recon_weight * recon_loss + self.seg_weight * seg_loss
+        return {"total_loss": total, "recon_loss": recon_loss, "seg_loss": seg_loss}
+
+
+def _batches(loader, device):
+    for batch in loader:
+        yield batch, batch["image"].to(device, non_blocking=True), batch["mask"].to(device, non_blocking=True)
+
+
+def train_epoch(model, train_loader, criterion, optimizer, device, epoch, step_hook=None):
+    """One epoch; returns batch-size-weighted means under the reference's keys."""
+    model.train()
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
+    count = 0
+    for _, images, masks in _batches(train_loader, device):
+        reconstruction, anomaly_map = model(images)
+        losses = criterion(reconstruction, anomaly_map, images, masks)
+        optimizer.zero_grad(set_to_none=True)
+        losses["total_loss"].backward()
+        if step_hook is not None:
+            step_hook()                     # data-parallel gradient exchange completes here
+        optimizer.step()
+        bs = images.size(0)
+        with torch.no_grad():
+            sums += bs * torch.stack([losses["total_loss"].detach(), losses["recon_loss"].detach(),
+                                      losses["seg_loss"].detach()]).double()
+        count += bs
+    t, r, s = (sums / max(count, 1)).tolist()
+    return {"total_loss": t, "recon_loss": r, "seg_loss": s}
+
+
+def validate_epoch(model, val_loader, criterion, device):
+    model.eval()
+    meters = {k: AverageMeter() for k in ("total_loss", "recon_loss", "seg_loss")}
+    labels, scores, masks_true, masks_pred = [], [], [], []
+    with torch.no_grad():
+        for batch, images, masks in _batches(val_loader, device):
+            reconstruction, anomaly_map = model(images)
+            losses = criterion(reconstruction, anomaly_map, images, masks)
+            bs = images.size(0)
+            for k, m in meters.items():
+                m.update(float(losses[k]), bs)
+            labels.extend(np.asarray(batch["label"]))
+            scores.extend(compute_anomaly_score(reconstruction, images).cpu().numpy())
+            masks_true.extend(masks.cpu().numpy())
+            masks_pred.extend(anomaly_map.cpu().numpy())
+    labels, scores = np.array(labels), np.array(scores)
+    masks_true, masks_pred = np.array(masks_true), np.array(masks_pred)
+
+    if len(np.unique(labels)) > 1:
+        threshold = np.percentile(scores, 95)
+        image_metrics = calculate_metrics(labels, (scores > threshold).astype(int), scores)
+    else:
+        normal = float(labels[0] == 0) if len(labels) else 0.0
+        image_metrics = {"accuracy": normal, "precision": 0.0, "recall": 0.0, "specificity": normal,
+                         "f1_score": 0.0, "auroc": 0.0, "auprc": 0.0}
+
+    pixel_metrics = {}
+    anomalous = labels == 1
+    if anomalous.sum() > 0:
+        truth = (masks_true[anomalous] > 0.5).astype(np.uint8).ravel()
+        if len(np.unique(truth)) > 1:
+            for thr in (0.3, 0.5, 0.7):
+                pred = (masks_pred[anomalous] > thr).astype(np.uint8).ravel()
+                pixel_metrics[f"pixel_f1_@{thr}"] = calculate_metrics(truth, pred)["f1_score"]
+
+    return {"total_loss": meters["total_loss"].avg, "recon_loss": meters["recon_loss"].avg,
+            "seg_loss": meters["seg_loss"].avg, "image_metrics": image_metrics, "pixel_metrics": pixel_metrics,
+            "predictions": {"labels": labels, "scores": scores, "masks_true": masks_true,
+                            "masks_pred": masks_pred}}
+
+
+def get_optimizer(model, optimizer_name="adam", learning_rate=1e-3, weight_decay=1e-4):
+    name = optimizer_name.lower()
+    params = model.parameters()
+    if name == "adam":
+        return torch.optim.Adam(params, lr=learning_rate, weight_decay=weight_decay)
+    if name == "adamw":
+        return torch.optim.AdamW(params, lr=learning_rate, weight_decay=weight_decay)
+    if name == "sgd":
+        return torch.optim.SGD(params, lr=learning_rate, momentum=0.9, weight_decay=weight_decay)
+    raise ValueError(f"Unknown optimizer: {optimizer_name}")
+
+
+def get_scheduler(optimizer, scheduler_name="cosine", num_epochs=100, eta_min=1e-6):
+    name = scheduler_name.lower()
+    sched = torch.optim.lr_scheduler
+    if name == "cosine":
+        return sched.CosineAnnealingLR(optimizer, T_max=num_epochs, eta_min=eta_min)
+    if name == "step":
+        return sched.StepLR(optimizer, step_size=num_epochs // 3, gamma=0.1)
+    if name == "plateau":
+        return sched.ReduceLROnPlateau(optimizer, mode="min", patience=10, factor=0.5)
+    return None
