@@ -33,7 +33,7 @@ def rnd(name, shape, kind="normal"):
 
 def q(t, dtype):
     """value the kernel actually sees (bf16 rounding of inputs)"""
-    return t.to(dtype).float()
+    return t.detach().to(dtype).float().clone()
 
 
 def nhwc(t, dtype):
