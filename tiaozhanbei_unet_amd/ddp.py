@@ -1,0 +1,132 @@
+"""Data parallelism for the training hot path: one process per GPU, gradients summed with RCCL
+all-reduce over xGMI (``torch.distributed`` backend "nccl" IS RCCL on ROCm), overlapped with backward.
+
+The reference is single-process; this is the one parallel strategy the path needs: images are
+independent, only the gradient (43.2 M fp32 = 172.9 MB for AnomalyUNet) is exchanged, once per step.
+
+Design for xGMI (7 point-to-point links per GPU, per-link bound rings): few, LARGE buckets.  Parameters
+are bucketed in REVERSE registration order (~ the order backward produces their gradients); each bucket is
+one flat fp32 buffer.  A post-accumulate hook copies a finished gradient into its slice; when the last
+slice of a bucket lands, the all-reduce of that bucket is enqueued asynchronously (RCCL's own stream, event
+chained to the compute stream), so the big decoder/bottleneck buckets travel while the encoder backward is
+still running.  ``finish()`` waits for the outstanding collectives before the optimiser step.  BatchNorm
+statistics stay per-GPU (standard DDP semantics).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+class GradientExchange:
+    """Bucketed, overlapped gradient averaging for ``params`` (any device torch.distributed supports)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 48 << 20, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.buckets: List[torch.Tensor] = []
+        self._slots = {}            # param -> (bucket index, view)
+        self._pending: List[int] = []
+        self._count: List[int] = []
+        self._handles = []
+        self._hooks = []
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"          # RCCL reduces with AVG in-kernel; gloo needs sum + scale
+        self._build(bucket_bytes)
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- layout -----------------------------------------------------------------------------
+    def _build(self, bucket_bytes: int) -> None:
+        order = list(reversed(self.params))
+        cur, cur_bytes, plan = [], 0, []
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                plan.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            plan.append(cur)
+        for bi, ps in enumerate(plan):
+            # every slice starts on a 16-byte boundary
+            sizes = [(p.numel() + 3) // 4 * 4 for p in ps]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p, sz in zip(ps, sizes):
+                self._slots[p] = (bi, flat[off:off + p.numel()].view_as(p))
+                off += sz
+            self.buckets.append(flat)
+            self._count.append(len(ps))
+        self._pending = list(self._count)
+
+    def bucket_sizes_mb(self):
+        return [round(b.numel() * 4 / 2 ** 20, 2) for b in self.buckets]
+
+    # -- start of training: identical replicas ----------------------------------------------------
+    def broadcast(self, tensors: Iterable[torch.Tensor], src: int = 0) -> None:
+        if self.world == 1:
+            return
+        for t in tensors:
+            dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=src, group=self.group)
+
+    # -- per step ---------------------------------------------------------------------------------
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        bi, view = self._slots[p]
+        view.copy_(p.grad)
+        p.grad = view                       # the optimiser reads the reduced bucket slice
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi: int) -> None:
+        flat = self.buckets[bi]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._handles.append((bi, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
+
+    def finish(self) -> None:
+        """Wait for every outstanding all-reduce (call between backward() and optimizer.step())."""
+        if self.world == 1:
+            return
+        for bi, left in enumerate(self._pending):
+            if 0 < left < self._count[bi]:      # some parameter of the bucket got no gradient this step
+                self._launch(bi)
+        for bi, h in self._handles:
+            h.wait()
+            if not self._avg:
+                self.buckets[bi].div_(self.world)
+        self._handles.clear()
+        self._pending = list(self._count)
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
+
+
+class DataParallel(torch.nn.Module):
+    """Thin wrapper: ``forward`` is the wrapped module's; ``finish_gradients()`` completes the exchange.
+    ``state_dict()`` is the wrapped module's (un-prefixed keys)."""
+
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 48 << 20, process_group=None):
+        super().__init__()
+        self.module = module
+        self.exchange = GradientExchange(module.parameters(), bucket_bytes, process_group)
+        self.exchange.broadcast(list(module.parameters()) + list(module.buffers()))
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish_gradients(self) -> None:
+        self.exchange.finish()
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)
