@@ -42,10 +42,27 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask, cgroup quota, and the GPU box's
+    per-GPU CPU share (16) when the container still sees every core of the host."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n if n <= 32 else 16
+
+
 def cpu_baseline(size, batch):
     """The oracle's train step (fwd + MSE/focal + bwd + Adam) on the host cores, bounded sample."""
     from oracle import unet_oracle as O, weights as W
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     state = dict(W.make_state(W.state_spec("anomaly_unet", 3, 1, False), 0))
     g = torch.Generator().manual_seed(42)
