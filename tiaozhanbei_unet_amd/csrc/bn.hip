@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int MAX_PARTS = 1024;
+constexpr int MAX_PARTS = 512;
 
 // MODE 0: sum y, sum y^2       MODE 1: sum dz, sum dz*yhat (dz = da*[fma(y,scale,shift) > 0])     MODE 2: sum x
 template <typename T, int MODE>
@@ -37,15 +37,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = istd[c0 + j]; }
   }
-  for (long long r = r_begin + tr; r < r_end; r += RPI) {
-    float v[PIECE];
-    Vec<T>::load(y + r * C + c0, v);
+  auto accum = [&](const float (&v)[PIECE], const float (&g)[PIECE]) {
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) { s0[j] += v[j]; s1[j] = fmaf(v[j], v[j], s1[j]); }
     } else if (MODE == 1) {
-      float g[PIECE];
-      Vec<T>::load(da + r * C + c0, g);
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) {
         const float z = fmaf(v[j], sc[j], sh[j]);
@@ -57,6 +53,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) s0[j] += v[j];
     }
+  };
+  long long r = r_begin + tr;
+  for (; r + 3 * RPI < r_end; r += 4 * RPI) {      // 4 independent 16-byte loads in flight per tensor
+    float v[4][PIECE], g[4][PIECE];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      Vec<T>::load(y + (r + u * RPI) * C + c0, v[u]);
+      if (MODE == 1) Vec<T>::load(da + (r + u * RPI) * C + c0, g[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accum(v[u], g[u]);
+  }
+  for (; r < r_end; r += RPI) {
+    float v[PIECE], g[PIECE];
+    Vec<T>::load(y + r * C + c0, v);
+    if (MODE == 1) Vec<T>::load(da + r * C + c0, g);
+    accum(v, g);
   }
 #pragma unroll
   for (int j = 0; j < PIECE; ++j) { red[0][tr][tc * PIECE + j] = s0[j]; red[1][tr][tc * PIECE + j] = s1[j]; }
@@ -70,19 +83,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
   }
 }
 
-// ordered fp64 sum of the block partials; 4 row-lanes per channel
-__device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][4][64],
+// ordered fp64 sum of the block partials: block = 16 channels x 16 row-lanes
+constexpr int FL = 16, FC = 16;
+__device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][FL][FC],
                                  double& a, double& b) {
   double s0 = 0.0, s1 = 0.0;
-  for (int k = rl; k < nparts; k += 4) {
+  for (int k = rl; k < nparts; k += FL) {
     s0 += (double)part[((size_t)k * 2 + 0) * C + c];
     s1 += (double)part[((size_t)k * 2 + 1) * C + c];
   }
-  red[0][rl][c & 63] = s0;
-  red[1][rl][c & 63] = s1;
+  red[0][rl][c % FC] = s0;
+  red[1][rl][c % FC] = s1;
   __syncthreads();
-  a = (red[0][0][c & 63] + red[0][1][c & 63]) + (red[0][2][c & 63] + red[0][3][c & 63]);
-  b = (red[1][0][c & 63] + red[1][1][c & 63]) + (red[1][2][c & 63] + red[1][3][c & 63]);
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int i = 0; i < FL; ++i) { a += red[0][i][c % FC]; b += red[1][i][c % FC]; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
@@ -90,8 +105,8 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* __restrict__ save_mean, float* __restrict__ save_istd, float* __restrict__ scale,
     float* __restrict__ shift) {
-  __shared__ double red[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  __shared__ double red[2][FL][FC];
+  const int c = blockIdx.x * FC + (threadIdx.x % FC), rl = threadIdx.x / FC;
   double s, ss;
   sum_parts(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
@@ -112,21 +127,32 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
   }
 }
 
+// dgamma, dbeta and the three per-channel coefficients of  dy = A*dz + B*y + K
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double red[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+                                                              float inv_count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ istd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coefs) {
+  __shared__ double red[2][FL][FC];
+  const int c = blockIdx.x * FC + (threadIdx.x % FC), rl = threadIdx.x / FC;
   double s, ss;
   sum_parts(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
-  dbeta[c] = (float)s;
-  dgamma[c] = (float)ss;
+  const float db = (float)s, dg = (float)ss;
+  dbeta[c] = db;
+  dgamma[c] = dg;
+  const float A = gamma[c] * istd[c];
+  const float B = -A * istd[c] * dg * inv_count;
+  coefs[c] = A;
+  coefs[C + c] = B;
+  coefs[2 * C + c] = -A * db * inv_count - B * mean[c];
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                               float* __restrict__ out) {
-  __shared__ double red[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  __shared__ double red[2][FL][FC];
+  const int c = blockIdx.x * FC + (threadIdx.x % FC), rl = threadIdx.x / FC;
   double s, ss;
   sum_parts(part, nparts, C, c, rl, red, s, ss);
   if (rl == 0) out[c] = (float)s;
@@ -142,51 +168,113 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
   shift[c] = fmaf(-rm[c], sc, beta[c]);
 }
 
-template <typename T>
+// FAST: (256*PIECE) % C == 0, so a thread's channel group never changes along the grid-stride loop and its
+// coefficients live in registers; 2 independent 16-byte accesses in flight.  Otherwise a generic modulo path.
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, long long pieces, int C,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, T* __restrict__ a) {
   constexpr int PIECE = ET<T>::PIECE;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pieces;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)((i * PIECE) % C);
-    float v[PIECE];
-    Vec<T>::load(y + i * PIECE, v);
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (FAST) {
+    const int c0 = (threadIdx.x * PIECE) % C;
+    float sc[PIECE], sh[PIECE];
 #pragma unroll
-    for (int j = 0; j < PIECE; ++j) v[j] = fmaxf(fmaf(v[j], scale[c0 + j], shift[c0 + j]), 0.f);
-    Vec<T>::store(a + i * PIECE, v);
+    for (int j = 0; j < PIECE; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    for (; i + stride < pieces; i += 2 * stride) {
+      float v0[PIECE], v1[PIECE];
+      Vec<T>::load(y + i * PIECE, v0);
+      Vec<T>::load(y + (i + stride) * PIECE, v1);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) { v0[j] = fmaxf(fmaf(v0[j], sc[j], sh[j]), 0.f); v1[j] = fmaxf(fmaf(v1[j], sc[j], sh[j]), 0.f); }
+      Vec<T>::store(a + i * PIECE, v0);
+      Vec<T>::store(a + (i + stride) * PIECE, v1);
+    }
+    for (; i < pieces; i += stride) {
+      float v[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+      Vec<T>::store(a + i * PIECE, v);
+    }
+  } else {
+    const int groups = C / PIECE;
+    for (; i < pieces; i += stride) {
+      const int c0 = (int)(i % groups) * PIECE;
+      float v[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) v[j] = fmaxf(fmaf(v[j], scale[c0 + j], shift[c0 + j]), 0.f);
+      Vec<T>::store(a + i * PIECE, v);
+    }
   }
 }
 
-// dy = gamma*istd * (dz - dbeta/M - yhat*dgamma/M)
-template <typename T>
+// dy = A*dz + B*y + K   (== gamma*istd * (dz - dbeta/M - yhat*dgamma/M)),  dz = da*[fma(y,scale,shift) > 0]
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
-    const T* __restrict__ da, const T* __restrict__ y, long long pieces, int C, float inv_count,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ istd,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ dgamma,
-    const float* __restrict__ dbeta, T* __restrict__ dy) {
+    const T* __restrict__ da, const T* __restrict__ y, long long pieces, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ coefs, T* __restrict__ dy) {
   constexpr int PIECE = ET<T>::PIECE;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pieces;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)((i * PIECE) % C);
-    float v[PIECE], g[PIECE];
-    Vec<T>::load(y + i * PIECE, v);
-    Vec<T>::load(da + i * PIECE, g);
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (FAST) {
+    const int c0 = (threadIdx.x * PIECE) % C;
+    float sc[PIECE], sh[PIECE], A[PIECE], B[PIECE], K[PIECE];
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) {
-      const int c = c0 + j;
-      const float z = fmaf(v[j], scale[c], shift[c]);
-      const float dz = z > 0.f ? g[j] : 0.f;
-      const float yhat = (v[j] - mean[c]) * istd[c];
-      g[j] = gamma[c] * istd[c] * (dz - dbeta[c] * inv_count - yhat * dgamma[c] * inv_count);
+      sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+      A[j] = coefs[c0 + j]; B[j] = coefs[C + c0 + j]; K[j] = coefs[2 * C + c0 + j];
     }
-    Vec<T>::store(dy + i * PIECE, g);
+    for (; i + stride < pieces; i += 2 * stride) {
+      float v0[PIECE], g0[PIECE], v1[PIECE], g1[PIECE];
+      Vec<T>::load(y + i * PIECE, v0);
+      Vec<T>::load(da + i * PIECE, g0);
+      Vec<T>::load(y + (i + stride) * PIECE, v1);
+      Vec<T>::load(da + (i + stride) * PIECE, g1);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const float d0 = fmaf(v0[j], sc[j], sh[j]) > 0.f ? g0[j] : 0.f;
+        const float d1 = fmaf(v1[j], sc[j], sh[j]) > 0.f ? g1[j] : 0.f;
+        g0[j] = fmaf(A[j], d0, fmaf(B[j], v0[j], K[j]));
+        g1[j] = fmaf(A[j], d1, fmaf(B[j], v1[j], K[j]));
+      }
+      Vec<T>::store(dy + i * PIECE, g0);
+      Vec<T>::store(dy + (i + stride) * PIECE, g1);
+    }
+    for (; i < pieces; i += stride) {
+      float v[PIECE], g[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+      Vec<T>::load(da + i * PIECE, g);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const float d = fmaf(v[j], sc[j], sh[j]) > 0.f ? g[j] : 0.f;
+        g[j] = fmaf(A[j], d, fmaf(B[j], v[j], K[j]));
+      }
+      Vec<T>::store(dy + i * PIECE, g);
+    }
+  } else {
+    const int groups = C / PIECE;
+    for (; i < pieces; i += stride) {
+      const int c0 = (int)(i % groups) * PIECE;
+      float v[PIECE], g[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+      Vec<T>::load(da + i * PIECE, g);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const int c = c0 + j;
+        const float d = fmaf(v[j], scale[c], shift[c]) > 0.f ? g[j] : 0.f;
+        g[j] = fmaf(coefs[c], d, fmaf(coefs[C + c], v[j], coefs[2 * C + c]));
+      }
+      Vec<T>::store(dy + i * PIECE, g);
+    }
   }
 }
 
 struct RedPlan { int nparts, rows_per_block; };
 RedPlan red_plan(long long pixels, int C) {
-  long long want = 2048 / (C / 64);
+  long long want = 1024 / (C / 64);
   if (want < 1) want = 1;
   if (want > MAX_PARTS) want = MAX_PARTS;
   long long rpb = cdiv64(pixels, want);
@@ -206,13 +294,13 @@ int32_t launch_reduce(const void* y, const void* da, long long pixels, int C, co
   return unet_check_launch("colreduce_kernel");
 }
 
-inline int ew_blocks(long long pieces) { return (int)std::min<long long>(cdiv64(pieces, 256), 256 * 16); }
+inline int ew_blocks(long long pieces) { return (int)std::min<long long>(cdiv64(pieces, 512), 256 * 8); }
 
 }  // namespace
 
 extern "C" size_t unet_bn_workspace(int64_t pixels, int32_t c) {
   (void)pixels;
-  return (size_t)MAX_PARTS * 2 * (size_t)c * sizeof(float);
+  return ((size_t)MAX_PARTS * 2 + 3) * (size_t)c * sizeof(float);
 }
 
 int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, float* out, float* ws,
@@ -230,7 +318,7 @@ int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, fl
                    ? launch_reduce<bf16_t, 2>(x, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, ws, pl, s)
                    : launch_reduce<float, 2>(x, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, ws, pl, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 64), dim3(256), 0, s, ws, pl.nparts, C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / FC), dim3(256), 0, s, ws, pl.nparts, C, out);
   return unet_check_launch("colsum_finalize_kernel");
 }
 
@@ -255,7 +343,7 @@ extern "C" int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pix
                    ? launch_reduce<bf16_t, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s)
                    : launch_reduce<float, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / 64), dim3(256), 0, s, part, pl.nparts, c, (double)pixels,
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, (double)pixels,
                      gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale, shift);
   return unet_check_launch("bn_finalize_train_kernel");
 }
@@ -278,12 +366,20 @@ extern "C" int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixe
   ProfScope prof(UNET_K_BN, 0.0, s);
   if (dtype == UNET_BF16) {
     const long long pieces = pixels * c / 8;
-    hipLaunchKernelGGL(bn_relu_apply_kernel<bf16_t>, dim3(ew_blocks(pieces)), dim3(256), 0, s, (const bf16_t*)y,
-                       pieces, c, scale, shift, (bf16_t*)a);
+    if ((256 * 8) % c == 0)
+      hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a);
+    else
+      hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a);
   } else {
     const long long pieces = pixels * c / 4;
-    hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3(ew_blocks(pieces)), dim3(256), 0, s, (const float*)y,
-                       pieces, c, scale, shift, (float*)a);
+    if ((256 * 4) % c == 0)
+      hipLaunchKernelGGL((bn_relu_apply_kernel<float, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)y, pieces, c, scale, shift, (float*)a);
+    else
+      hipLaunchKernelGGL((bn_relu_apply_kernel<float, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)y, pieces, c, scale, shift, (float*)a);
   }
   return unet_check_launch("bn_relu_apply_kernel");
 }
@@ -296,29 +392,38 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
                UNET_ERR_BAD_ARG, "unet_bn_relu_bwd: null pointer");
   UNET_REQUIRE(pixels > 0 && c > 0 && c % 64 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_relu_bwd: c=%d", c);
   const RedPlan pl = red_plan(pixels, c);
-  UNET_REQUIRE(workspace_bytes >= (size_t)pl.nparts * 2 * c * sizeof(float), UNET_ERR_WORKSPACE,
+  const size_t part_bytes = (size_t)pl.nparts * 2 * c * sizeof(float);
+  UNET_REQUIRE(workspace_bytes >= part_bytes + (size_t)3 * c * sizeof(float), UNET_ERR_WORKSPACE,
                "unet_bn_relu_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s);
   float* part = (float*)workspace;
+  float* coefs = part + (size_t)pl.nparts * 2 * c;
   int32_t rc = dtype == UNET_BF16
                    ? launch_reduce<bf16_t, 1>(y, da, pixels, c, scale, shift, save_mean, save_istd, part, pl, s)
                    : launch_reduce<float, 1>(y, da, pixels, c, scale, shift, save_mean, save_istd, part, pl, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c / 64), dim3(256), 0, s, part, pl.nparts, c, dgamma, dbeta);
+  const float inv = (float)(1.0 / (double)pixels);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
+                     save_mean, save_istd, dgamma, dbeta, coefs);
   rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
-  const float inv = (float)(1.0 / (double)pixels);
   if (dtype == UNET_BF16) {
     const long long pieces = pixels * c / 8;
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                       (const bf16_t*)da, (const bf16_t*)y, pieces, c, inv, gamma, save_mean, save_istd, scale,
-                       shift, dgamma, dbeta, (bf16_t*)dy);
+    if ((256 * 8) % c == 0)
+      hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<bf16_t, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)da, (const bf16_t*)y, pieces, c, scale, shift, coefs, (bf16_t*)dy);
+    else
+      hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<bf16_t, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)da, (const bf16_t*)y, pieces, c, scale, shift, coefs, (bf16_t*)dy);
   } else {
     const long long pieces = pixels * c / 4;
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                       (const float*)da, (const float*)y, pieces, c, inv, gamma, save_mean, save_istd, scale,
-                       shift, dgamma, dbeta, (float*)dy);
+    if ((256 * 4) % c == 0)
+      hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<float, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)da, (const float*)y, pieces, c, scale, shift, coefs, (float*)dy);
+    else
+      hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<float, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)da, (const float*)y, pieces, c, scale, shift, coefs, (float*)dy);
   }
   return unet_check_launch("bn_relu_bwd_apply_kernel");
 }

@@ -130,22 +130,28 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     part[(size_t)blockIdx.x * CO * stride + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int CO, int Cin,
-                                         float* __restrict__ dw, float* __restrict__ db) {
+// one block per output element group: 256 threads sum the block partials of 4 outputs (64 lanes each)
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int CO,
+                                                                int Cin, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
   const int stride = Cin + 1;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= CO * stride) return;
   double s = 0.0;
-  for (int k = 0; k < nblocks; ++k) s += (double)part[(size_t)k * CO * stride + i];
-  const int co = i / stride, c = i % stride;
-  if (c < Cin) dw[co * Cin + c] = (float)s;
-  else db[co] = (float)s;
+  for (int k = lane; k < nblocks; k += 64) s += (double)part[(size_t)k * CO * stride + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) {
+    const int co = i / stride, c = i % stride;
+    if (c < Cin) dw[co * Cin + c] = (float)s;
+    else db[co] = (float)s;
+  }
 }
 
 inline int head_blocks(long long pixels, int tpp) {
   const long long per_block = 256 / tpp;
   long long b = cdiv64(pixels, per_block * 8);   // ~8 pixels per slot
-  if (b > 2048) b = 2048;
+  if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -222,7 +228,7 @@ extern "C" int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out,
   }
   int32_t rc = unet_check_launch("head_bwd_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(c_out * (c_in + 1), 128)), dim3(128), 0, s,
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(c_out * (c_in + 1), 4)), dim3(256), 0, s,
                      (const float*)workspace, nb, c_out, c_in, dweight, dbias);
   return unet_check_launch("head_bwd_finalize_kernel");
 }

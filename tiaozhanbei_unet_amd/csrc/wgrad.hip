@@ -198,20 +198,27 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void wgrad_kernel(cons
   }
 }
 
-// out[r][c][tap] (fp32, r < rows_out, c < cols_out) = sum_s partial[s][tap][r][c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int split,
-                                    int taps, int Crow, int Ccol, int rows_out, int cols_out) {
-  const long long total = (long long)rows_out * cols_out * taps;
+// out[r][c][tap] (fp32, r < rows_out, c < cols_out) = sum_s partial[s][tap][r][c], fixed order.
+// One thread per (r, c): slab reads are coalesced along c, the TAPS results of a thread are contiguous.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ out, int split, int Crow, int Ccol,
+                                                           int rows_out, int cols_out) {
+  const long long total = (long long)rows_out * cols_out;
+  const size_t plane = (size_t)Crow * Ccol, slab = (size_t)TAPS * plane;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % taps);
-    const long long rc = i / taps;
-    const int c = (int)(rc % cols_out), r = (int)(rc / cols_out);
-    const size_t slab = (size_t)taps * Crow * Ccol;
-    const float* p = partial + ((size_t)tap * Crow + r) * Ccol + c;
-    float s = 0.f;
-    for (int k = 0; k < split; ++k) s += p[(size_t)k * slab];
-    out[i] = s;
+    const int c = (int)(i % cols_out), r = (int)(i / cols_out);
+    const float* p = partial + (size_t)r * Ccol + c;
+    float s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+    for (int k = 0; k < split; ++k) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) s[t] += p[(size_t)k * slab + (size_t)t * plane];
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) out[i * TAPS + t] = s[t];
   }
 }
 
@@ -226,7 +233,7 @@ Plan make_plan(int n, int h, int w, int crow, int ccol) {
   p.nR = crow / 64;
   p.nC = ccol / 64;
   const long long ntiles = (long long)n * p.tilesY * p.tilesX;
-  long long want = 1024 / ((long long)p.nR * p.nC);
+  long long want = 512 / ((long long)p.nR * p.nC);
   if (want < 1) want = 1;
   if (want > ntiles) want = ntiles;
   p.tilesPerSplit = (int)cdiv64(ntiles, want);
@@ -253,10 +260,10 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
     int32_t rc = unet_check_launch("wgrad_kernel");
     if (rc) return rc;
-    const long long total = (long long)rows_out * cols_out * TAPS;
+    const long long total = (long long)rows_out * cols_out;
     const int rb = (int)std::min<long long>(cdiv64(total, 256), 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, P.partial, out, pl.split, TAPS, P.Crow,
-                       P.Ccol, rows_out, cols_out);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<TAPS>, dim3(rb), dim3(256), 0, s, (const float*)P.partial, out, pl.split,
+                       P.Crow, P.Ccol, rows_out, cols_out);
   }
   return unet_check_launch("wgrad_reduce_kernel");
 }
