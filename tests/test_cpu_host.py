@@ -71,3 +71,35 @@ def test_product_does_not_import_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle", ""), f"{fn} mentions the oracle package"
+
+
+def test_cli_flags_match_reference_contract():
+    """Flag names/defaults of src/train.py:38-97 and src/test.py:26-61 (pinned here as data)."""
+    from tiaozhanbei_unet_amd import test as test_cli
+    from tiaozhanbei_unet_amd import train as train_cli
+    a = train_cli.parse_args([])
+    ref = dict(data_root="../datasets/mvtec_anomaly_detection", category="bottle", image_size=256,
+               model="anomaly_unet", bilinear=False, epochs=100, batch_size=16, learning_rate=1e-3,
+               weight_decay=1e-4, optimizer="adam", scheduler="cosine", recon_weight=1.0, seg_weight=1.0,
+               use_ssim=False, num_workers=4, device="auto", seed=42, save_dir="../outputs", save_freq=10,
+               resume=None, val_freq=5, debug=False, debug_samples=20)
+    for k, v in ref.items():
+        assert getattr(a, k) == v, k
+    t = test_cli.parse_args(["--checkpoint", "x.pth"])
+    assert t.pixel_thresholds == [0.3, 0.5, 0.7] and t.output_dir == "../test_results" and t.threshold is None
+
+
+def test_mvtec_reader_contract(tmp_path):
+    from tiaozhanbei_unet_amd.dataset import get_available_categories, get_dataloaders, write_synthetic_mvtec
+    root = write_synthetic_mvtec(str(tmp_path), "bottle", n_train=3, n_good=2, n_bad=2, size=40)
+    assert get_available_categories(root) == ["bottle"]
+    train, test = get_dataloaders(root, "bottle", batch_size=2, image_size=32, num_workers=0)
+    b = next(iter(train))
+    assert set(b) == {"image", "mask", "label", "anomaly_type", "image_path"}
+    assert b["image"].shape == (2, 3, 32, 32) and b["mask"].shape == (2, 1, 32, 32)
+    assert float(b["mask"].max()) == 0.0 and int(b["label"].sum()) == 0            # train split = good only
+    labels, mx = [], 0.0
+    for b in test:
+        labels += b["label"].tolist(); mx = max(mx, float(b["mask"].max()))
+    assert sorted(labels) == [0, 0, 1, 1]
+    assert 0 < mx <= 1.0 / 255.0 + 1e-9, "masks are {0,1} uint8 scaled by 1/255 (reference quirk)"

@@ -221,3 +221,33 @@ def test_properties_at_benchmark_size():
         r, a = m(torch.randn(4, 3, 256, 256, device=DEV))
     assert r.shape == (4, 3, 256, 256) and a.shape == (4, 1, 256, 256)
     assert float(r.min()) >= 0 and float(r.max()) <= 1 and bool(torch.isfinite(a).all())
+
+
+@pytest.mark.parametrize("model", ["anomaly_unet", "unet"])
+def test_cli_train_then_test_roundtrip(tmp_path, model):
+    """BASELINE configs[0]-style plumbing (2 epochs, bs=4) through the train/test CLIs on an MVTec-layout toy
+    tree: output tree, args.json, checkpoint dict keys and training_results.json keys of the reference."""
+    import json
+    import os
+    from tiaozhanbei_unet_amd import test as test_cli
+    from tiaozhanbei_unet_amd import train as train_cli
+    from tiaozhanbei_unet_amd.dataset import write_synthetic_mvtec
+    root = write_synthetic_mvtec(str(tmp_path / "data"), "bottle", n_train=8, n_good=3, n_bad=3, size=64)
+    exp = train_cli.main(["--data_root", root, "--category", "bottle", "--model", model, "--epochs", "2",
+                          "--batch_size", "4", "--image_size", "64", "--num_workers", "0", "--val_freq", "1",
+                          "--save_freq", "1", "--save_dir", str(tmp_path / "out")])
+    for d in ("checkpoints", "results", "visualizations", "logs"):
+        assert os.path.isdir(os.path.join(exp, d))
+    res = json.load(open(os.path.join(exp, "results", "training_results.json")))
+    assert set(res) == {"train_losses", "val_losses", "best_val_loss", "total_epochs", "total_params", "args"}
+    assert len(res["train_losses"]) == 2 and all(l == l for l in res["train_losses"])
+    assert res["total_params"] == (43228228 if model == "anomaly_unet" else 31037633)
+    ck = os.path.join(exp, "checkpoints", "checkpoint_epoch_1.pth")
+    sd = torch.load(ck, map_location="cpu", weights_only=True)
+    assert set(sd) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+    assert "inc.double_conv.0.weight" in sd["model_state_dict"]
+    out = test_cli.main(["--data_root", root, "--category", "bottle", "--model", model, "--checkpoint", ck,
+                         "--batch_size", "4", "--image_size", "64", "--num_workers", "0",
+                         "--output_dir", str(tmp_path / "test_out")])
+    tm = json.load(open(os.path.join(out, "test_metrics.json")))
+    assert {"image_metrics", "pixel_metrics", "threshold", "args"} <= set(tm)

@@ -1,0 +1,117 @@
+"""torchvision-free MVTec-AD reader with the reference's batch contract (host-side I/O).
+
+Mirrors /root/reference/src/dataset.py: directory layout and label rules (:38-89), the batch dict keys
+`image, mask, label, anomaly_type, image_path` (:121-127), resize + ImageNet normalisation (:134-146) and
+the reference's mask quirk -- masks are binarised to {0,1} uint8 and then scaled by 1/255 (:101-103,:149-152),
+so targets are {0, 1/255}.  torchvision is absent from this environment, so transforms are PIL + numpy
+(ColorJitter is not reproduced; flip and +-10 degree rotation are).  `write_synthetic_mvtec` creates a small
+MVTec-layout tree of PNGs for CLI plumbing tests; `--synthetic` in train.py uses it.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import random
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader, Dataset
+
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
+
+
+def _image_tensor(img: Image.Image, size, train: bool) -> torch.Tensor:
+    img = img.resize((size[1], size[0]), Image.BILINEAR)
+    if train:
+        if random.random() < 0.5:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        img = img.rotate(random.uniform(-10.0, 10.0), resample=Image.NEAREST)
+    a = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0
+    return torch.from_numpy((a - MEAN) / STD)
+
+
+def _mask_tensor(mask: Image.Image, size) -> torch.Tensor:
+    mask = mask.resize((size[1], size[0]), Image.BILINEAR)
+    return torch.from_numpy(np.asarray(mask, dtype=np.float32)[None] / 255.0)   # ToTensor() on a {0,1} uint8 image
+
+
+class MVTecDataset(Dataset):
+    def __init__(self, root_dir, category, split="train", image_size=256, is_train=True):
+        self.size = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
+        self.split, self.is_train = split, is_train
+        self.image_paths, self.mask_paths, self.labels, self.anomaly_types = [], [], [], []
+        cat = os.path.join(root_dir, category)
+        if split == "train":
+            self._add(sorted(glob.glob(os.path.join(cat, "train", "good", "*.png"))), 0, "good", None)
+        else:
+            test_dir, gt_dir = os.path.join(cat, "test"), os.path.join(cat, "ground_truth")
+            self._add(sorted(glob.glob(os.path.join(test_dir, "good", "*.png"))), 0, "good", None)
+            if not is_train and os.path.isdir(test_dir):
+                for kind in sorted(os.listdir(test_dir)):
+                    d = os.path.join(test_dir, kind)
+                    if kind != "good" and os.path.isdir(d):
+                        self._add(sorted(glob.glob(os.path.join(d, "*.png"))), 1, kind, os.path.join(gt_dir, kind))
+
+    def _add(self, images, label, kind, mask_dir):
+        for p in images:
+            m = None
+            if mask_dir is not None:
+                cand = os.path.join(mask_dir, os.path.basename(p).replace(".png", "_mask.png"))
+                m = cand if os.path.exists(cand) else None
+            self.image_paths.append(p); self.mask_paths.append(m)
+            self.labels.append(label); self.anomaly_types.append(kind)
+
+    def __len__(self):
+        return len(self.image_paths)
+
+    def __getitem__(self, i):
+        img = Image.open(self.image_paths[i]).convert("RGB")
+        if self.mask_paths[i]:
+            m = (np.asarray(Image.open(self.mask_paths[i]).convert("L")) > 0).astype(np.uint8)
+        else:
+            m = np.zeros((img.size[1], img.size[0]), dtype=np.uint8)
+        train_aug = self.split == "train"
+        return {"image": _image_tensor(img, self.size, train_aug), "mask": _mask_tensor(Image.fromarray(m), self.size),
+                "label": self.labels[i], "anomaly_type": self.anomaly_types[i], "image_path": self.image_paths[i]}
+
+
+def get_dataloaders(root_dir, category, batch_size=16, image_size=256, num_workers=4):
+    train = MVTecDataset(root_dir, category, "train", image_size, is_train=True)
+    test = MVTecDataset(root_dir, category, "test", image_size, is_train=False)
+    kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available())
+    return DataLoader(train, shuffle=True, **kw), DataLoader(test, shuffle=False, **kw)
+
+
+def get_available_categories(root_dir):
+    if not os.path.isdir(root_dir):
+        return []
+    return sorted(d for d in os.listdir(root_dir)
+                  if not d.startswith(".") and os.path.isdir(os.path.join(root_dir, d, "train"))
+                  and os.path.isdir(os.path.join(root_dir, d, "test")))
+
+
+def write_synthetic_mvtec(root_dir, category="bottle", n_train=8, n_good=4, n_bad=4, size=64, seed=0):
+    """A tiny MVTec-layout tree of random PNGs (train/good, test/good, test/broken, ground_truth/broken)."""
+    rng = np.random.default_rng(seed)
+    cat = os.path.join(root_dir, category)
+
+    def put(sub, n, with_mask=False):
+        d = os.path.join(cat, *sub)
+        os.makedirs(d, exist_ok=True)
+        for i in range(n):
+            img = rng.integers(0, 256, (size, size, 3), dtype=np.uint8)
+            Image.fromarray(img).save(os.path.join(d, f"{i:03d}.png"))
+            if with_mask:
+                md = os.path.join(cat, "ground_truth", sub[-1])
+                os.makedirs(md, exist_ok=True)
+                m = np.zeros((size, size), dtype=np.uint8)
+                y, x = rng.integers(0, size // 2, 2)
+                m[y:y + size // 4, x:x + size // 4] = 255
+                Image.fromarray(m).save(os.path.join(md, f"{i:03d}_mask.png"))
+
+    put(("train", "good"), n_train)
+    put(("test", "good"), n_good)
+    put(("test", "broken"), n_bad, with_mask=True)
+    return root_dir
