@@ -97,7 +97,10 @@ def validate_epoch(model, val_loader, criterion, device):
             for k, m in meters.items():
                 m.update(float(losses[k]), bs)
             labels.extend(np.asarray(batch["label"]))
-            scores.extend(compute_anomaly_score(reconstruction, images).cpu().numpy())
+            # image-level score = mean of the per-pixel error map.  (The reference keeps the whole map here
+            # and then compares N labels with N*H*W predictions, which raises in sklearn as soon as both
+            # classes are present, src/train_utils.py:194,206-210 -- a defect we do not reproduce.)
+            scores.extend(compute_anomaly_score(reconstruction, images).flatten(1).mean(1).cpu().numpy())
             masks_true.extend(masks.cpu().numpy())
             masks_pred.extend(anomaly_map.cpu().numpy())
     labels, scores = np.array(labels), np.array(scores)
