@@ -18,6 +18,8 @@
 //   LDS rows are padded by 16 B so ds_read_b128 fragments are bank-conflict free.
 // The skip concat (src/model.py:65) and centre pad (src/model.py:57-61) are two source views:
 //   a chunk reads from src[0] or src[1]; out-of-view pixels read as zero.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -460,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const IgemmParams P) {
       const int set = (PAR + tap) & 1;
       store_b(breg[set], set);
       __syncthreads();
-      load_b(breg[set], c, tap + 2);
-      if (tap == 6) load_a(c + 1);
+      if (tap + 2 < 9 || c + 1 < nchunks) load_b(breg[set], c, tap + 2);   // uniform branch; no loads past the end
+      if (tap == 6 && c + 1 < nchunks) load_a(c + 1);
       compute((tap / 3) * C::RS + (tap % 3) * C::PSTR, set);
     }
     if (c + 1 < nchunks) {
@@ -540,6 +542,191 @@ int32_t launch3(const IgemmParams& P, int kclass, hipStream_t s) {
   return unet_check_launch("conv3_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// conv3_ws_kernel: weight-stationary 3x3 convolution for the wide-spatial / narrow-channel layers
+// (64 input channels: inc.*, up4.conv.3, their data gradients, the 128-row dgrad of up4.conv.0).
+// These layers are HBM-bound (AI ~ 288 FLOP/B at bf16), their whole filter bank is tiny (9*64*Cout bf16),
+// and the per-tap weight staging + barrier of the generic kernel dominated their run time.  Here every
+// wave keeps ITS 32 output channels x 576 K of weights in REGISTERS (36 MFMA A-fragments = 144 VGPRs,
+// loaded once per block straight from global memory) and the block streams pixel tiles: the halo'd patch
+// of tile t+1 is prefetched (buffer loads -> registers) while tile t computes and lands in the other LDS
+// buffer; one barrier per tile, no weight traffic through LDS at all, 72 MFMAs per wave between barriers.
+struct CfgWS {
+  static constexpr int WTH = 16, WTW = 16, WNPIX = WTH * WTW;   // 256-pixel tiles: halo overhead 1.27x
+  static constexpr int HH = WTH + 2, HW = WTW + 2;
+  static constexpr int PSTR = 128 + 16;
+  static constexpr int RS = (HW * PSTR + 255) / 256 * 256;
+  static constexpr int PIECES = HH * (RS / 16);                 // 16-byte pieces of the padded image (pads included)
+  static constexpr int NWAVE = 8;                               // 512 threads: 2 (channels) x 4 (pixels)
+  static constexpr int NINSTR = (PIECES + 63) / 64;             // 1 KiB LDS-DMA instructions per patch
+  static constexpr int NDMA = (NINSTR + NWAVE - 1) / NWAVE;     // per wave per tile (surplus ones hit a dummy KiB)
+  static constexpr int A_BYTES = NINSTR * 1024;
+  static constexpr int NBUF = 3;                                // patch ring: 2 tiles in flight behind the one computing
+  static constexpr int LDS = NBUF * A_BYTES + 1024;             // + dummy target of the surplus (all-OOB) DMAs
+  static constexpr int PXT = 2;                                 // 64 pixels per wave
+  static constexpr int ROWS = 64;                               // output channels per block
+};
+
+__global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, int tiles_per_block) {
+  using C = CfgWS;
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave & 1, wpx = wave >> 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int nCg = P.Cout / C::ROWS;
+  // channel groups of one tile range sit on the SAME XCD (b % 8) in adjacent dispatch slots, so the
+  // second group finds the patches in that XCD's L2
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cg = slot % nCg, tr = (slot / nCg) * 8 + xcd;
+  const int co_lane = cg * C::ROWS + wco * 32 + l31;
+  const int tiles_img = P.tilesX * P.tilesY;
+  const int total_tiles = P.N * tiles_img;
+  const int t_begin = tr * tiles_per_block;
+  const int t_end = min(t_begin + tiles_per_block, total_tiles);
+  if (t_begin >= t_end) return;
+
+  // ---- this wave's weights -> registers: A fragment (tap, kg) = W[co_lane][tap][16*kg + 8*hh .. +7]
+  bf16x8 wreg[36];
+  {
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(P.w);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+        wreg[tap * 4 + kg] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(tap * P.Cout + co_lane)) * P.wK + kg * 16 + hh * 8);
+    // retire the weight loads HERE (vmcnt(0)), through the builtin so hipcc's wait bookkeeping sees it:
+    // otherwise it places counted waits for them inside the tile loop, which would drain the DMA ring.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+
+  int boff[C::PXT];
+#pragma unroll
+  for (int pt = 0; pt < C::PXT; ++pt) {
+    const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
+    boff[pt] = (m >> 4) * C::RS + (m & 15) * C::PSTR + hh * 16;
+  }
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const DView S = P.src[0];
+  // LDS-DMA staging (buffer_load_dwordx4 ... lds): the padded LDS image is filled LINEARLY, 1 KiB per wave
+  // instruction; pad pieces and out-of-image halo pixels use an out-of-range voffset and land as zeros.
+  // No staging registers: whole patches are in flight while this tile computes.
+  int a_code[C::NDMA];            // hy | hx << 8 | part << 16   (-1: pad piece)
+#pragma unroll
+  for (int j = 0; j < C::NDMA; ++j) {
+    const int q = (j * C::NWAVE + wave) * 64 + lane;              // instruction index j*NWAVE + wave
+    const int hy = q / (C::RS / 16), rem = q - hy * (C::RS / 16);
+    const int hx = rem / 9, part = rem - hx * 9;
+    a_code[j] = (hy < C::HH && hx < C::HW && part < 8) ? (hy | (hx << 8) | (part << 16)) : -1;
+  }
+  const unsigned img_bytes = (unsigned)S.H * S.W * S.C * 2u;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  auto dma_a = [&](int tile, int buf) {
+    const int n = tile / tiles_img, r = tile - n * tiles_img;
+    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(S.p + (size_t)n * img_bytes), (short)0, (int)img_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+      const int code = a_code[j];
+      const int hy = code & 255, hx = (code >> 8) & 255, part = (code >> 16) & 255;
+      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+      const bool ok = code >= 0 && y >= 0 && y < S.H && x >= 0 && x < S.W;
+      const unsigned vo = ok ? (unsigned)((y * S.W + x) * S.C * 2 + part * 16) : OOB;
+      const int idx = j * C::NWAVE + wave;                          // wave-uniform
+      char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, 0, 0, 0);
+    }
+  };
+
+  // ring of NBUF patches: tile k computes from slot k % NBUF while the DMAs of tiles k+1, k+2 are in flight.
+  // Waits are COUNTED (vmcnt counts loads, DMAs and stores in issue order): before tile k at least the DMAs
+  // of tile k+1 (NDMA ops) are younger than tile k's, so vmcnt(NDMA) retires tile k's patch without
+  // draining the prefetch; raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
+#pragma unroll
+  for (int d = 0; d < C::NBUF - 1; ++d)
+    if (t_begin + d < t_end) dma_a(t_begin + d, d);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int k = tile - t_begin;
+    const int cur = k % C::NBUF;
+    if (tile + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
+
+    f32x16 acc[C::PXT];
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
+    const char* pb = smem + cur * C::A_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * C::RS + (tap % 3) * C::PSTR;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt) {
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + toff + kg * 32);
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap * 4 + kg], fb, acc[pt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue for this tile
+    const int n = tile / tiles_img, r = tile - n * tiles_img;
+    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt) {
+      const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
+      const int fy = ty0 + (m >> 4), fx = tx0 + (m & 15);
+      if (fy < P.H && fx < P.W) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int co = cg * C::ROWS + wco * 32 + 8 * g + 4 * hh;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[pt][4 * g + j];
+          const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
+          if (co >= P.dst_split) co -= P.dst_split;
+          const int y = fy - D.oy, x = fx - D.ox;
+          if (y >= 0 && y < D.H && x >= 0 && x < D.W) {
+            T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
+            bf16x4 rr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x4*>(o) = rr;
+          }
+        }
+      }
+    }
+  }
+}
+
+int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s) {
+  using C = CfgWS;
+  auto kern = conv3_ws_kernel;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  P.tilesX = cdiv(P.W, C::WTW);
+  P.tilesY = cdiv(P.H, C::WTH);
+  const long long tiles = (long long)P.N * P.tilesY * P.tilesX;
+  const int nCg = P.Cout / C::ROWS;
+  int tpb = (int)cdiv64(tiles * nCg, 256);        // one resident block per CU, one round
+  if (tpb < 2) tpb = 2;
+  const long long ranges8 = cdiv64(cdiv64(tiles, tpb), 8) * 8;      // tile ranges, padded to a multiple of 8 (XCDs)
+  const long long blocks = ranges8 * nCg;
+  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
+  ProfScope prof(kclass, flops, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P, tpb);
+  return unet_check_launch("conv3_ws_kernel");
+}
+
 template <typename T, int TAPS, int BN, int KG>
 int32_t launch(const IgemmParams& P, int kclass, hipStream_t s) {
   using C = Cfg<T, TAPS, BN, KG>;
@@ -571,7 +758,20 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s) {
   P.nCo = P.Cout / (big ? 128 : 64);
   P.tilesX = cdiv(P.W, TW);
   P.tilesY = cdiv(P.H, TH);
+  static const char* impl_env = nullptr;
+  impl_env = getenv("UNET_CONV_IMPL");          // tuning hook: "0" = generic igemm_kernel, default conv3_kernel
+  const bool use3 = !(impl_env && impl_env[0] == '0');
+  if constexpr (TAPS == 9 && sizeof(T) == 2) {
+    // 64-channel inputs: weight-stationary streaming kernel (impl "2" forces it off)
+    const bool ws_ok = P.Ctot == 64 && P.src[1].C == 0 && !P.accumulate &&
+                       !(impl_env && (impl_env[0] == '0' || impl_env[0] == '2'));
+    if (ws_ok) return launch_ws(P, kclass, s);
+  }
   if constexpr (TAPS == 9) {
+    if (!use3 || P.Ctot < 2 * CK4) {
+      if (big) return k4 ? launch<T, TAPS, 128, 4>(P, kclass, s) : launch<T, TAPS, 128, 1>(P, kclass, s);
+      return k4 ? launch<T, TAPS, 64, 4>(P, kclass, s) : launch<T, TAPS, 64, 1>(P, kclass, s);
+    }
     if (big) return k4 ? launch3<T, 128, 4>(P, kclass, s) : launch3<T, 128, 1>(P, kclass, s);
     return k4 ? launch3<T, 64, 4>(P, kclass, s) : launch3<T, 64, 1>(P, kclass, s);
   } else {

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--op", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--ab", default="", help="comma list of UNET_CONV_IMPL values to A/B interleaved in one process")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -59,17 +60,25 @@ def main():
         wp = ops.pack_weight(wt, L.PACK_CONVT_FWD, co, ci, dt)
         flops = 2.0 * n * h * w * co * ci * 4
         run = lambda: L.check(lib.unet_convt2x2_fwd(ops._DT[dt], n, h, w, p(x), ci, p(wp), p(b), p(y), co, st), "convt")
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.iters
-    print(f"{a.kind} {a.op} n={n} {ci}->{co} {h}x{w} {a.dtype}: {ms * 1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
+    variants = a.ab.split(",") if a.ab else [None]
+    best = {v: 1e9 for v in variants}
+    for rnd in range(4 if a.ab else 1):
+        for v in variants:
+            if v is not None:
+                os.environ["UNET_CONV_IMPL"] = v
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
+    for v, ms in best.items():
+        tag = "" if v is None else f" impl={v}"
+        print(f"{a.kind} {a.op} n={n} {ci}->{co} {h}x{w} {a.dtype}{tag}: {ms * 1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
