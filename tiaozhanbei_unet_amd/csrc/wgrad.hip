@@ -12,6 +12,8 @@
 // so bf16 fragments are fetched with ds_read_b64_tr_b16 (hardware transpose, gfx950); fp32 fragments are
 // plain ds_read_b32 (one pixel per lane-half).  Partial slabs go to a caller workspace and are summed in
 // a fixed order by reduce_kernel -> bitwise reproducible gradients.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -222,6 +224,190 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad_dma_kernel: bf16 conv3x3 weight gradient with LDS-DMA staging (buffer_load ... lds).
+// Same math and tiling as wgrad_kernel<bf16,9>; differences:
+//  * the dY tile and the halo'd X patch of tile t+1 are DMA'd into the second LDS buffer while tile t runs
+//    its 72 MFMAs per wave -- no staging registers (180 instead of 220 VGPRs), global latency hidden;
+//  * LDS rows are the natural 128 B (64 channels) with a 16-byte-piece XOR swizzle, piece ^= ((row>>1)&1)<<2,
+//    applied on the DMA's per-lane SOURCE address and on the transposed reads; four consecutive pixel rows
+//    of a ds_read_b64_tr_b16 then sit in four different 64-byte bank quarters (conflict-free) and a buffer is
+//    39 KB instead of 59 KB, so two blocks still fit a CU with double buffering.
+struct WDma {
+  static constexpr int TH = 8, TW = 16, NPIX = 128, HH = 10, HW = 18;
+  static constexpr int R_INSTR = NPIX * 8 / 64;                 // 16 x 1 KiB
+  static constexpr int C_INSTR = (HH * HW * 8 + 63) / 64;       // 23 x 1 KiB (last one half used)
+  static constexpr int R_BYTES = R_INSTR * 1024, C_BYTES = C_INSTR * 1024;
+  static constexpr int BUF = R_BYTES + C_BYTES;
+  static constexpr int NINSTR = R_INSTR + C_INSTR;              // 39
+  static constexpr int NDMA = (NINSTR + 3) / 4;                 // 10 per wave (one surplus -> dummy KiB)
+  static constexpr int LDS = 2 * BUF + 1024;
+};
+
+__device__ inline bf16x8 tr_frag2(const char* base, int off0, int off1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) {
+  using C = WDma;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int b = blockIdx.x;
+  const int ctile = b % P.nC;  b /= P.nC;
+  const int rtile = b % P.nR;
+  const int sp = b / P.nR;
+  int cch = ctile * 64;
+  const WView CS = (cch < P.ct[0].C) ? P.ct[0] : P.ct[1];
+  if (cch >= P.ct[0].C) cch -= P.ct[0].C;
+  const int rch = rtile * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read lane geometry (see wgrad_kernel): kq = pixel offset in the 16-pixel k group,
+  // lane byte offset inside the wave's 64 bytes of channels
+  const int g = lane >> 4, i16 = lane & 15;
+  const int kq = 8 * (g >> 1) + (i16 >> 2);
+  const int chb = (16 * (g & 1) + 4 * (i16 & 3)) * 2;
+  const int r_piece = (wr * 64 + chb) >> 4, r_sub = (wr * 64 + chb) & 15;
+  const int c_piece = (wc * 64 + chb) >> 4, c_sub = (wc * 64 + chb) & 15;
+  const int r_swz = (((kq >> 1) & 1) << 2);                    // row = ty*16 + kq (+4): bit 1 of kq
+
+  // ---- DMA descriptors: instruction ii = j*4 + wave; < R_INSTR -> dY tile, else X patch
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  int d_code[C::NDMA];      // row | piece << 12 | isC << 16    (-1: surplus)
+#pragma unroll
+  for (int j = 0; j < C::NDMA; ++j) {
+    const int ii = j * 4 + wave;
+    int code = -1;
+    if (ii < C::R_INSTR) {
+      const int row = ii * 8 + (lane >> 3), pp = lane & 7;
+      code = row | ((pp ^ (((row >> 1) & 1) << 2)) << 12);
+    } else if (ii < C::NINSTR) {
+      const int q = (ii - C::R_INSTR) * 64 + lane;
+      const int row = q >> 3, pp = q & 7;
+      if (row < C::HH * C::HW) code = row | ((pp ^ (((row >> 1) & 1) << 2)) << 12) | (1 << 16);
+    }
+    d_code[j] = code;
+  }
+  const unsigned r_img = (unsigned)P.rt.H * P.rt.W * P.rt.C * 2u;
+  const unsigned c_img = (unsigned)CS.H * CS.W * CS.C * 2u;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  auto dma = [&](int tile, int buf) {
+    int t = tile;
+    const int txi = t % P.tilesX;  t /= P.tilesX;
+    const int tyi = t % P.tilesY;
+    const int n = t / P.tilesY;
+    const int ty0 = tyi * C::TH, tx0 = txi * C::TW;
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(P.rt.p + (size_t)n * r_img), (short)0, (int)r_img, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(CS.p + (size_t)n * c_img), (short)0, (int)c_img, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+      const int ii = j * 4 + wave;                             // wave-uniform
+      const int code = d_code[j];
+      const int row = code & 4095, piece = (code >> 12) & 15;
+      char* dst = smem + 2 * C::BUF;                           // dummy KiB for the surplus instruction
+      if (ii < C::R_INSTR) {
+        dst = smem + buf * C::BUF + ii * 1024;
+        const int y = ty0 + (row >> 4), x = tx0 + (row & 15);
+        const bool ok = y < P.H && x < P.W;
+        const unsigned vo = ok ? (unsigned)(((y * P.rt.W + x) * P.rt.C + rch) * 2 + piece * 16) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vo, 0, 0, 0);
+      } else {
+        if (ii < C::NINSTR) dst = smem + buf * C::BUF + C::R_BYTES + (ii - C::R_INSTR) * 1024;
+        const int hy = row / C::HW, hx = row - hy * C::HW;
+        const int y = ty0 + hy - 1 - CS.oy, x = tx0 + hx - 1 - CS.ox;
+        const bool ok = code >= 0 && y >= 0 && y < CS.H && x >= 0 && x < CS.W;
+        const unsigned vo = ok ? (unsigned)(((y * CS.W + x) * CS.C + cch) * 2 + piece * 16) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void*)dst, 16, vo, 0, 0, 0);
+      }
+    }
+  };
+
+  const int ntiles = P.N * P.tilesY * P.tilesX;
+  const int t_begin = sp * P.tilesPerSplit;
+  const int t_end = min(t_begin + P.tilesPerSplit, ntiles);
+
+  if (t_begin < t_end) dma(t_begin, 0);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int buf = (tile - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile `tile` has landed
+    __builtin_amdgcn_s_barrier();                               // ... everyone's has; buffer buf^1 is free
+    if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
+    const char* sR = smem + buf * C::BUF;
+    const char* sC = sR + C::R_BYTES;
+#pragma unroll 1
+    for (int ty = 0; ty < C::TH; ++ty) {
+      const int rrow = ty * C::TW + kq;
+      const int rp = rrow * 128 + ((r_piece ^ r_swz) << 4) + r_sub;
+      const bf16x8 fa = tr_frag2(sR, rp, rp + 4 * 128);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int crow = (ty + tap / 3) * C::HW + kq + tap % 3;
+        const int cp = crow * 128 + ((c_piece ^ (((crow >> 1) & 1) << 2)) << 4) + c_sub;
+        const bf16x8 fb = tr_frag2(sC, cp, cp + 4 * 128);       // rows +4: same swizzle bit
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+
+  const int col = ctile * 64 + wc * 32 + l31;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    float* o = P.partial + ((size_t)(sp * 9 + tap) * P.Crow) * P.Ccol;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rtile * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      o[(size_t)row * P.Ccol + col] = acc[tap][r];
+    }
+  }
+}
+
+// Many splits, few outputs (the 64-channel layers: 512 slabs of 9x64x64): one block per (row, 64 columns,
+// tap), 4 slab-lanes per output, combined in a fixed order through LDS.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial,
+                                                                float* __restrict__ out, int split, int Crow,
+                                                                int Ccol, int rows_out, int cols_out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  int b = blockIdx.x;
+  const int tap = b % TAPS;  b /= TAPS;
+  const int nchunk = (cols_out + 63) / 64;
+  const int c = (b % nchunk) * 64 + cl, r = b / nchunk;
+  const size_t plane = (size_t)Crow * Ccol, slab = (size_t)TAPS * plane;
+  float s = 0.f;
+  if (c < cols_out) {
+    const float* p = partial + (size_t)tap * plane + (size_t)r * Ccol + c;
+    int k = ks;
+    for (; k + 12 < split; k += 16) {
+      const float a0 = p[(size_t)k * slab], a1 = p[(size_t)(k + 4) * slab], a2 = p[(size_t)(k + 8) * slab],
+                  a3 = p[(size_t)(k + 12) * slab];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < split; k += 4) s += p[(size_t)k * slab];
+  }
+  red[ks][cl] = s;
+  __syncthreads();
+  if (ks == 0 && c < cols_out)
+    out[((size_t)r * cols_out + c) * TAPS + tap] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 struct Plan { int tilesX, tilesY, nR, nC, split, tilesPerSplit; size_t bytes; };
 
 template <int TAPS>
@@ -257,13 +443,34 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
   {
     ProfScope prof(kclass, flops, s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
+    const char* impl = getenv("UNET_WGRAD_IMPL");               // tuning hook: "0" = register-staged kernel
+    if constexpr (sizeof(T) == 2 && TAPS == 9) {
+      if (!(impl && impl[0] == '0')) {
+        static bool dma_attr = false;
+        if (!dma_attr) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WDma::LDS);
+          dma_attr = true;
+        }
+        hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
+      } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
+      }
+    } else {
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
+    }
     int32_t rc = unet_check_launch("wgrad_kernel");
     if (rc) return rc;
-    const long long total = (long long)rows_out * cols_out;
-    const int rb = (int)std::min<long long>(cdiv64(total, 256), 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<TAPS>, dim3(rb), dim3(256), 0, s, (const float*)P.partial, out, pl.split,
-                       P.Crow, P.Ccol, rows_out, cols_out);
+    if (pl.split >= 16) {
+      const long long rb = (long long)rows_out * ((cols_out + 63) / 64) * TAPS;
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel<TAPS>, dim3((unsigned)rb), dim3(256), 0, s, (const float*)P.partial,
+                         out, pl.split, P.Crow, P.Ccol, rows_out, cols_out);
+    } else {
+      const long long total = (long long)rows_out * cols_out;
+      const int rb = (int)std::min<long long>(cdiv64(total, 256), 4096);
+      hipLaunchKernelGGL(wgrad_reduce_kernel<TAPS>, dim3(rb), dim3(256), 0, s, (const float*)P.partial, out, pl.split,
+                         P.Crow, P.Ccol, rows_out, cols_out);
+    }
   }
   return unet_check_launch("wgrad_reduce_kernel");
 }

@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--op", default="fwd", choices=["fwd", "dgrad", "wgrad"])
-    ap.add_argument("--ab", default="", help="comma list of UNET_CONV_IMPL values to A/B interleaved in one process")
+    ap.add_argument("--ab", default="", help="comma list of values of --abvar to A/B interleaved in one process")
+    ap.add_argument("--abvar", default="UNET_CONV_IMPL")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -65,7 +66,7 @@ def main():
     for rnd in range(4 if a.ab else 1):
         for v in variants:
             if v is not None:
-                os.environ["UNET_CONV_IMPL"] = v
+                os.environ[a.abvar] = v
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
