@@ -87,6 +87,15 @@ enum unet_pack_mode {
 int32_t unet_pack_weight(const float* w, void* out, int32_t c_out, int32_t c_in, int32_t rows,
                          int32_t k, int32_t mode, int32_t dtype, void* stream);
 
+/* All of a model's weights in ONE launch (after each optimiser step): `descs` is a DEVICE array of n
+ * descriptors (the fields of unet_pack_weight; dtype is per call). */
+typedef struct unet_pack_desc {
+  const float* w;
+  void* out;
+  int32_t c_out, c_in, rows, k, mode, reserved;
+} unet_pack_desc;
+int32_t unet_pack_weights_batched(const unet_pack_desc* descs, int32_t n, int32_t dtype, void* stream);
+
 /* ---- 3x3 convolution, pad 1, stride 1, no bias (nn.Conv2d at src/model.py:14,17) ------ */
 /* y = conv(concat(src[0], src[1])) as an implicit GEMM on MFMA.  Output channels below
  * dst_split go to dst[0], the rest to dst[1] (dst[1].ptr may be NULL when dst_split == c_out).

@@ -40,6 +40,7 @@ SIGNATURES = {
     "unet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_pack_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_pack_weights_batched": (_i, [_p, _i, _i, _p]),
     "unet_conv3x3": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, C.POINTER(View), _i, _i, _i, _p]),
     "unet_conv3x3_wgrad_workspace": (_z, [_i, _i, _i, _i, _i]),
     "unet_conv3x3_wgrad": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _i, _p, _z, _p]),

@@ -82,6 +82,36 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// every weight of the model in one launch: blockIdx.y = descriptor, 32-bit index math
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const unet_pack_desc* __restrict__ descs) {
+  const unet_pack_desc d = descs[blockIdx.y];
+  const unsigned K = (unsigned)d.k, rows = (unsigned)d.rows;
+  const unsigned Co = (unsigned)d.c_out, Ci = (unsigned)d.c_in;
+  const unsigned taps = d.mode <= UNET_PACK_CONV_DGRAD ? 9u : 4u;
+  const unsigned total = taps * rows * K;
+  const float* __restrict__ w = d.w;
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    float v = 0.f;
+    const unsigned kk = i % K, t = i / K;
+    if (d.mode == UNET_PACK_CONV_FWD) {
+      const unsigned co = t % rows, tap = t / rows;
+      if (co < Co && kk < Ci) v = w[(co * Ci + kk) * 9u + tap];
+    } else if (d.mode == UNET_PACK_CONV_DGRAD) {
+      const unsigned ci = t % rows, tap = t / rows;
+      if (kk < Co && ci < Ci) v = w[(kk * Ci + ci) * 9u + (8u - tap)];
+    } else if (d.mode == UNET_PACK_CONVT_FWD) {
+      const unsigned co = t % rows, z = t / rows;
+      if (co < Co && kk < Ci) v = w[(kk * Co + co) * 4u + z];
+    } else {
+      const unsigned z = t % 4u, ci = t / 4u;
+      if (kk < Co && ci < Ci) v = w[(ci * Co + kk) * 4u + z];
+    }
+    out[i] = ET<T>::from_f(v);
+  }
+}
+
 // ------------------------------------------------------------------------------- max pool 2x2
 template <typename T>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
@@ -308,6 +338,17 @@ extern "C" int32_t unet_pack_weight(const float* w, void* out, int32_t c_out, in
   else
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (float*)out, c_out, c_in, rows, k, mode, total);
   return unet_check_launch("pack_weight_kernel");
+}
+
+extern "C" int32_t unet_pack_weights_batched(const unet_pack_desc* descs, int32_t n, int32_t dtype, void* stream) {
+  UNET_REQUIRE(descs && n > 0 && n <= 65535, UNET_ERR_BAD_ARG, "unet_pack_weights_batched: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_PACK, 0.0, s);
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(64, n), dim3(256), 0, s, descs);
+  else
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(64, n), dim3(256), 0, s, descs);
+  return unet_check_launch("pack_weights_batched_kernel");
 }
 
 #define EW_DISPATCH(NAME, KERN, TOTAL, ...)                                                                 \

@@ -141,6 +141,31 @@ class OutConv(_HipBlock):
         return ops.Head.apply(x, self.conv.weight, self.conv.bias, sigmoid)
 
 
+def _pack_cache(model):
+    """One batched weight-pack launch per parameter update for the whole model (ops.PackCache)."""
+    dtype = model.compute_dtype
+    cache = model.__dict__.get("_packs")
+    if cache is None or cache.dtype != dtype:
+        cache = ops.PackCache(dtype)
+        for mod in model.modules():
+            if isinstance(mod, DoubleConv):
+                for idx in (0, 3):
+                    w = mod.double_conv[idx].weight
+                    co, ci = w.shape[0], w.shape[1]
+                    ctot = (ci + 63) // 64 * 64
+                    cache.add(w, ops.L.PACK_CONV_FWD, co, ctot)
+                    cache.add(w, ops.L.PACK_CONV_DGRAD, ctot, co)
+            elif isinstance(mod, Up) and not mod.bilinear:
+                w = mod.up.weight
+                ci, co = w.shape[0], w.shape[1]
+                cache.add(w, ops.L.PACK_CONVT_FWD, co, ci)
+                cache.add(w, ops.L.PACK_CONVT_DGRAD, ci, co)
+        model.__dict__["_packs"] = cache
+    cache.refresh()
+    ops.set_active_packs(cache)
+    return cache
+
+
 def _encoder(m, x):
     x1 = m.inc(x)
     x2 = m.down1(x1)
@@ -170,6 +195,8 @@ class UNet(_HipBlock):
         self.outc = OutConv(64, n_classes, precision=precision)
 
     def forward(self, x):
+        ops._require_cuda(x)
+        _pack_cache(self)
         x1, x2, x3, x4, x5 = _encoder(self, x)
         y = self.up1(x5, x4)
         y = self.up2(y, x3)
@@ -208,6 +235,8 @@ class AnomalyUNet(_HipBlock):
         return getattr(self, f"outc_{branch}")(y, sigmoid=True)
 
     def forward(self, x):
+        ops._require_cuda(x)
+        _pack_cache(self)
         feats = _encoder(self, x)
         reconstruction = self._decode(feats, "recon")
         anomaly_map = self._decode(feats, "seg")

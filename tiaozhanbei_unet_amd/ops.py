@@ -146,6 +146,78 @@ def pack_weight(w: torch.Tensor, mode: int, rows: int, k: int, dtype) -> torch.T
     return out
 
 
+class PackCache:
+    """Packed GEMM-layout copies of a model's conv / convT weights, refreshed by ONE batched launch whenever a
+    parameter changed (its autograd version counter moved), instead of ~70 small pack launches per step."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.items = []        # (weight, mode, rows, k)
+        self.slots = {}        # (id(weight), mode) -> [packed view, rows, k, version]
+        self.table = None
+        self.ptrs = None
+
+    def add(self, weight, mode, rows, k):
+        if (id(weight), mode) not in self.slots:
+            self.items.append((weight, mode, rows, k))
+            self.slots[(id(weight), mode)] = [None, rows, k, -1]
+
+    def _build(self):
+        import numpy as np
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        sizes = [(9 if m <= L.PACK_CONV_DGRAD else 4) * r * k for (_, m, r, k) in self.items]
+        offs = [0]
+        for s_ in sizes:
+            offs.append(offs[-1] + (s_ + 7) // 8 * 8)
+        dev = self.items[0][0].device
+        self.buf = torch.empty(offs[-1], dtype=self.dtype, device=dev)
+        rec = np.zeros(len(self.items), dtype=[("w", "<u8"), ("out", "<u8"), ("c_out", "<i4"), ("c_in", "<i4"),
+                                               ("rows", "<i4"), ("k", "<i4"), ("mode", "<i4"), ("pad", "<i4")])
+        for i, (w, m, r, k) in enumerate(self.items):
+            view = self.buf[offs[i]:offs[i] + sizes[i]]
+            co, ci = (w.shape[0], w.shape[1]) if m <= L.PACK_CONV_DGRAD else (w.shape[1], w.shape[0])
+            rec[i] = (w.data_ptr(), view.data_ptr(), co, ci, r, k, m, 0)
+            self.slots[(id(w), m)][0] = view
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self.ptrs = [w.data_ptr() for (w, _, _, _) in self.items]
+
+    def refresh(self):
+        if not self.items:
+            return
+        if self.table is None or self.ptrs != [w.data_ptr() for (w, _, _, _) in self.items]:
+            self._build()
+            stale = True
+        else:
+            stale = any(self.slots[(id(w), m)][3] != w._version for (w, m, _, _) in self.items)
+        if stale:
+            L.check(L.lib().unet_pack_weights_batched(_ptr(self.table), len(self.items), _DT[self.dtype], _stream()),
+                    "unet_pack_weights_batched")
+            for (w, m, _, _) in self.items:
+                self.slots[(id(w), m)][3] = w._version
+
+    def get(self, weight, mode, rows, k):
+        s_ = self.slots.get((id(weight), mode))
+        if s_ is not None and s_[0] is not None and s_[1] == rows and s_[2] == k and s_[3] == weight._version:
+            return s_[0]
+        return None
+
+
+_active_packs = None
+
+
+def set_active_packs(cache):
+    global _active_packs
+    _active_packs = cache
+
+
+def packed(weight, mode, rows, k, dtype):
+    if _active_packs is not None and _active_packs.dtype == dtype:
+        hit = _active_packs.get(weight, mode, rows, k)
+        if hit is not None:
+            return hit
+    return pack_weight(weight, mode, rows, k, dtype)
+
+
 # ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
 class ConvBnRelu(torch.autograd.Function):
     """relu(batch_norm(conv3x3(cat([x0, x1])))) -- one third of DoubleConv
@@ -170,7 +242,7 @@ class ConvBnRelu(torch.autograd.Function):
         if not (ci <= ctot < ci + 64):
             raise ValueError(f"conv weight expects {ci} input channels, activations carry {ctot}")
         lib, st, dev = L.lib(), _stream(), x0.device
-        wp = pack_weight(weight, L.PACK_CONV_FWD, co, ctot, dtype)
+        wp = packed(weight, L.PACK_CONV_FWD, co, ctot, dtype)
         y = _nhwc_empty(n, co, h, w, dtype, dev)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         dst = _views([(y, 0, 0), None])
@@ -223,7 +295,7 @@ class ConvBnRelu(torch.autograd.Function):
                     "unet_conv3x3_wgrad")
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            wp = pack_weight(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
+            wp = packed(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
             dx0 = _nhwc_empty(n, c0, h, w, dtype, dev)
             if x1 is not None:
                 dx1 = _nhwc_empty(*x1.shape, dtype, dev)
@@ -270,7 +342,7 @@ class ConvT2x2(torch.autograd.Function):
         n, ci, h, w = x.shape
         co = weight.shape[1]
         dtype = x.dtype
-        wp = pack_weight(weight, L.PACK_CONVT_FWD, co, ci, dtype)
+        wp = packed(weight, L.PACK_CONVT_FWD, co, ci, dtype)
         y = _nhwc_empty(n, co, 2 * h, 2 * w, dtype, x.device)
         L.check(L.lib().unet_convt2x2_fwd(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(wp), _ptr(bias), _ptr(y), co,
                                           _stream()), "unet_convt2x2_fwd")
@@ -287,7 +359,7 @@ class ConvT2x2(torch.autograd.Function):
         dy = _as_nhwc(dy, dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            wp = pack_weight(weight, L.PACK_CONVT_DGRAD, ci, co, dtype)
+            wp = packed(weight, L.PACK_CONVT_DGRAD, ci, co, dtype)
             dx = _nhwc_empty(n, ci, h, w, dtype, dev)
             L.check(lib.unet_convt2x2_dgrad(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(dx), ci, st),
                     "unet_convt2x2_dgrad")
