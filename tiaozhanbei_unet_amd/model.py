@@ -161,7 +161,7 @@ def _pack_cache(model):
                 cache.add(w, ops.L.PACK_CONVT_FWD, co, ci)
                 cache.add(w, ops.L.PACK_CONVT_DGRAD, ci, co)
         model.__dict__["_packs"] = cache
-    cache.refresh()
+    cache.refresh(force=model.training)
     ops.set_active_packs(cache)
     return cache
 
