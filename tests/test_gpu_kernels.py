@@ -381,3 +381,24 @@ def test_cpu_tensors_are_refused(hip):
     from tiaozhanbei_unet_amd import DoubleConv
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         DoubleConv(64, 64)(torch.zeros(1, 64, 8, 8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_batched_weight_pack_matches_single_packs(hip, dtype):
+    """unet_pack_weights_batched (LDS-tiled, one launch) == unet_pack_weight for every layout, incl. zero padding."""
+    L, ops = hip
+    ws = [(rnd("pw0", (64, 3, 3, 3)), L.PACK_CONV_FWD, 64, 64), (rnd("pw0", (64, 3, 3, 3)), L.PACK_CONV_DGRAD, 64, 64),
+          (rnd("pw1", (128, 64, 3, 3)), L.PACK_CONV_FWD, 128, 64), (rnd("pw1", (128, 64, 3, 3)), L.PACK_CONV_DGRAD, 64, 128),
+          (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_FWD, 64, 128), (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_DGRAD, 128, 64)]
+    cache = ops.PackCache(dtype)
+    dev_ws = {}
+    for w, mode, rows, k in ws:
+        wd = dev_ws.setdefault(id(w), w.to(dev()))
+        cache.add(wd, mode, rows, k)
+    cache.refresh(force=True)
+    for w, mode, rows, k in ws:
+        wd = dev_ws[id(w)]
+        got = cache.get(wd, mode, rows, k)
+        assert got is not None
+        want = ops.pack_weight(wd, mode, rows, k, dtype)
+        assert torch.equal(got.float().cpu(), want.float().cpu()), f"mode {mode}"

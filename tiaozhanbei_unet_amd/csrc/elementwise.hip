@@ -82,33 +82,51 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
-// every weight of the model in one launch: blockIdx.y = descriptor, 32-bit index math
+// every weight of the model in one launch: blockIdx.y = descriptor.  The parameter is w[a][b][taps]
+// (conv: a=co, b=ci, 9 taps; convT: a=ci, b=co, 4 taps).  A block moves one tile through LDS so that BOTH
+// the fp32 reads (runs of TB*taps floats) and the packed writes (runs of 64 elements along the GEMM K axis)
+// are coalesced: tile 8(a) x 64(b) when the output is contiguous along b, 64(a) x 8(b) when along a.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const unet_pack_desc* __restrict__ descs) {
+  __shared__ float tile[64 * 8 * 9 + 64];
   const unet_pack_desc d = descs[blockIdx.y];
-  const unsigned K = (unsigned)d.k, rows = (unsigned)d.rows;
-  const unsigned Co = (unsigned)d.c_out, Ci = (unsigned)d.c_in;
-  const unsigned taps = d.mode <= UNET_PACK_CONV_DGRAD ? 9u : 4u;
-  const unsigned total = taps * rows * K;
+  const int mode = d.mode;
+  const bool conv = mode <= UNET_PACK_CONV_DGRAD;
+  const int taps = conv ? 9 : 4;
+  const int As = conv ? d.c_out : d.c_in, Bs = conv ? d.c_in : d.c_out;     // source dims
+  const bool along_b = (mode == UNET_PACK_CONV_FWD || mode == UNET_PACK_CONVT_DGRAD);
+  // padded extents of a and b in the OUTPUT
+  const int Ap = (mode == UNET_PACK_CONV_FWD || mode == UNET_PACK_CONVT_DGRAD) ? d.rows : d.k;
+  const int Bp = (mode == UNET_PACK_CONV_FWD || mode == UNET_PACK_CONVT_DGRAD) ? d.k : d.rows;
+  const int TA = along_b ? 8 : 64, TB = along_b ? 64 : 8;
+  const int nA = (Ap + TA - 1) / TA, nB = (Bp + TB - 1) / TB;
   const float* __restrict__ w = d.w;
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    float v = 0.f;
-    const unsigned kk = i % K, t = i / K;
-    if (d.mode == UNET_PACK_CONV_FWD) {
-      const unsigned co = t % rows, tap = t / rows;
-      if (co < Co && kk < Ci) v = w[(co * Ci + kk) * 9u + tap];
-    } else if (d.mode == UNET_PACK_CONV_DGRAD) {
-      const unsigned ci = t % rows, tap = t / rows;
-      if (kk < Co && ci < Ci) v = w[(kk * Ci + ci) * 9u + (8u - tap)];
-    } else if (d.mode == UNET_PACK_CONVT_FWD) {
-      const unsigned co = t % rows, z = t / rows;
-      if (co < Co && kk < Ci) v = w[(kk * Co + co) * 4u + z];
-    } else {
-      const unsigned z = t % 4u, ci = t / 4u;
-      if (kk < Co && ci < Ci) v = w[(ci * Co + kk) * 4u + z];
+  const int run = TB * taps;                       // contiguous source floats per a
+  for (int t = blockIdx.x; t < nA * nB; t += gridDim.x) {
+    const int a0 = (t / nB) * TA, b0 = (t % nB) * TB;
+    __syncthreads();
+    for (int i = threadIdx.x; i < TA * run; i += 256) {
+      const int al = i / run, r = i - al * run;
+      const int a = a0 + al, bb = b0 + r / taps;
+      tile[i] = (a < As && bb < Bs) ? w[((size_t)a * Bs + b0) * taps + r] : 0.f;
     }
-    out[i] = ET<T>::from_f(v);
+    __syncthreads();
+    // TA*TB*taps outputs; innermost = the 64-wide contiguous axis
+    for (int i = threadIdx.x; i < TA * TB * taps; i += 256) {
+      const int inner = i & 63, rest = i >> 6;
+      const int tap = rest % taps, outer = rest / taps;          // outer: the 8-wide axis
+      const int al = along_b ? outer : inner, bl = along_b ? inner : outer;
+      const int a = a0 + al, bb = b0 + bl;
+      if (a >= Ap || bb >= Bp) continue;
+      const float v = tile[al * run + bl * taps + tap];
+      size_t o;
+      if (mode == UNET_PACK_CONV_FWD) o = ((size_t)tap * d.rows + a) * d.k + bb;
+      else if (mode == UNET_PACK_CONV_DGRAD) o = ((size_t)(8 - tap) * d.rows + bb) * d.k + a;
+      else if (mode == UNET_PACK_CONVT_FWD) o = ((size_t)tap * d.rows + bb) * d.k + a;
+      else o = ((size_t)a * 4 + tap) * d.k + bb;
+      out[o] = ET<T>::from_f(v);
+    }
   }
 }
 
@@ -345,9 +363,9 @@ extern "C" int32_t unet_pack_weights_batched(const unet_pack_desc* descs, int32_
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_PACK, 0.0, s);
   if (dtype == UNET_BF16)
-    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(64, n), dim3(256), 0, s, descs);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(48, n), dim3(256), 0, s, descs);
   else
-    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(64, n), dim3(256), 0, s, descs);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(48, n), dim3(256), 0, s, descs);
   return unet_check_launch("pack_weights_batched_kernel");
 }
 
