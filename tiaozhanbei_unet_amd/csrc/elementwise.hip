@@ -7,25 +7,24 @@ namespace {
 inline int ew_blocks(long long items) { return (int)std::min<long long>(cdiv64(items, 256), 256 * 16); }
 
 // ------------------------------------------------------------------------------- layout
-// One thread per (pixel, 4-channel group): reads are coalesced along w per channel plane.
+// One thread per pixel: the C (<= 8 typical) plane reads are coalesced across threads, each thread then
+// writes its whole padded channel row with 16-byte stores (zeros beyond C).
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H,
-                                    int W, int Cp) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                           int N, int C, int H, int W, int Cp) {
+  constexpr int PIECE = ET<T>::PIECE;
   const long long hw = (long long)H * W;
-  const int groups = Cp / 4;
-  const long long total = (long long)N * hw * groups;
+  const long long total = (long long)N * hw;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i % hw;
-    const long long t = i / hw;
-    const int g = (int)(t % groups);
-    const long long n = t / groups;
-    T* o = dst + (n * hw + p) * Cp + g * 4;
+    const long long n = i / hw, p = i - n * hw;
+    const float* s = src + n * C * hw + p;
+    T* o = dst + i * Cp;
+    for (int c0 = 0; c0 < Cp; c0 += PIECE) {
+      float v[PIECE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = g * 4 + j;
-      const float v = c < C ? src[(n * C + c) * hw + p] : 0.f;
-      o[j] = ET<T>::from_f(v);
+      for (int j = 0; j < PIECE; ++j) v[j] = (c0 + j < C) ? s[(long long)(c0 + j) * hw] : 0.f;
+      Vec<T>::store(o + c0, v);
     }
   }
 }
@@ -313,10 +312,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 extern "C" int32_t unet_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
                                      int32_t c_pad, int32_t dtype, void* stream) {
   UNET_REQUIRE(src && dst, UNET_ERR_BAD_ARG, "unet_nchw_to_nhwc: null pointer");
-  UNET_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c && c_pad % 4 == 0, UNET_ERR_BAD_ARG,
-               "unet_nchw_to_nhwc: bad dims (c=%d c_pad=%d)", c, c_pad);
+  UNET_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c && c_pad % 8 == 0, UNET_ERR_BAD_ARG,
+               "unet_nchw_to_nhwc: bad dims (c=%d c_pad=%d, c_pad must be a multiple of 8)", c, c_pad);
   hipStream_t s = (hipStream_t)stream;
-  const long long total = (long long)n * h * w * (c_pad / 4);
+  const long long total = (long long)n * h * w;
   ProfScope prof(UNET_K_PACK, 0.0, s);
   if (dtype == UNET_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, src, (bf16_t*)dst, n, c, h, w, c_pad);

@@ -42,6 +42,7 @@ struct IgemmParams {
   int accumulate;
   int imul, gtaps;  // input position = frame*imul + gather tap (convT dgrad: 2, 4)
   int omul, nZ;     // output position = frame*omul + z tap     (convT fwd:   2, 4)
+  int zdiv;         // > 0: GEMM row = z*zdiv + co (convT fwd as one GEMM with 4*Cout rows)
   int tilesX, tilesY, nCo;
 };
 
@@ -224,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
   }
 
   // ---- epilogue: lane owns pixel (l31) and channels 8g+4h..+3 of each 32-row tile
-  const int zk = z >> 1, zl = z & 1;
 #pragma unroll
   for (int pt = 0; pt < C::PXT; ++pt) {
     const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         int co = co0 + wco * 64 + ct * 32 + 8 * g + 4 * hh;
+        int zz = z;
+        if (P.zdiv > 0) { zz = co / P.zdiv; co -= zz * P.zdiv; }
+        const int zk = zz >> 1, zl = zz & 1;
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][4 * g + j];
@@ -824,11 +827,13 @@ extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_
   P.src[0] = DView{(const char*)x, c_in, h, w, 0, 0};
   P.dst[0] = DViewW{(char*)y, c_out, 2 * h, 2 * w, 0, 0};
   P.N = n; P.H = h; P.W = w;
-  P.Ctot = c_in; P.Cout = c_out; P.wK = c_in;
+  // one GEMM with 4*c_out rows (row = z*c_out + co, the packed layout [4][c_out][c_in] read as one matrix):
+  // the input tile is staged once for all four sub-positions
+  P.Ctot = c_in; P.Cout = 4 * c_out; P.wK = c_in;
   P.w = (const char*)w_packed;
   P.bias = bias;
-  P.dst_split = c_out;
-  P.imul = 1; P.gtaps = 1; P.omul = 2; P.nZ = 4;
+  P.dst_split = 4 * c_out;
+  P.imul = 1; P.gtaps = 1; P.omul = 2; P.nZ = 1; P.zdiv = c_out;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UNET_BF16) return dispatch<bf16_t, 1>(P, UNET_K_CONVT_FWD, s);
   if (dtype == UNET_F32) return dispatch<float, 1>(P, UNET_K_CONVT_FWD, s);
