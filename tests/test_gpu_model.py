@@ -251,3 +251,29 @@ def test_cli_train_then_test_roundtrip(tmp_path, model):
                          "--output_dir", str(tmp_path / "test_out")])
     tm = json.load(open(os.path.join(out, "test_metrics.json")))
     assert {"image_metrics", "pixel_metrics", "threshold", "args"} <= set(tm)
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """The multi-rank path of bench.py (torch.distributed.run, DataParallel buckets, barrier/max timing, one JSON
+    line from rank 0) rehearsed with 2 ranks stacked on this one card over gloo (RCCL needs one GPU per rank;
+    the driver runs the real N=2/4/8 case)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UNET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "2", "--size", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 4
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
