@@ -149,11 +149,13 @@ def main():
 
     # ---- roofline of the dominant kernel class: hipEvent brackets inside libunet_hip, 2 extra steps
     roof = None
+    # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
     if rank == 0:
         ops.prof_enable(True)
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         prof = ops.prof_collect()
         ops.prof_enable(False)
         mfma = {k: v for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}

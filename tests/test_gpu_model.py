@@ -270,7 +270,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "2", "--size", "64"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
