@@ -77,6 +77,19 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
+    if a.ab and a.kind == "conv":
+        outs = {}
+        for v in variants:
+            os.environ[a.abvar] = v
+            tgt = {"fwd": y, "dgrad": dx, "wgrad": dw}[a.op]
+            tgt.zero_()
+            run()
+            torch.cuda.synchronize()
+            outs[v] = tgt.float().clone()
+        ref = outs[variants[0]]
+        for v in variants[1:]:
+            print(f"   check {a.abvar}={v} vs {variants[0]}: max|diff| {float((outs[v] - ref).abs().max()):.3e} "
+                  f"(|ref|max {float(ref.abs().max()):.3e})", flush=True)
     for v, ms in best.items():
         tag = "" if v is None else f" impl={v}"
         print(f"{a.kind} {a.op} n={n} {ci}->{co} {h}x{w} {a.dtype}{tag}: {ms * 1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
