@@ -362,9 +362,9 @@ extern "C" int32_t unet_pack_weights_batched(const unet_pack_desc* descs, int32_
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_PACK, 0.0, s);
   if (dtype == UNET_BF16)
-    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(48, n), dim3(256), 0, s, descs);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(224, n), dim3(256), 0, s, descs);
   else
-    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(48, n), dim3(256), 0, s, descs);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(224, n), dim3(256), 0, s, descs);
   return unet_check_launch("pack_weights_batched_kernel");
 }
 

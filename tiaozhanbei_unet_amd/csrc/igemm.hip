@@ -885,17 +885,30 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   };
 
   // ring of NBUF patches: tile k computes from slot k % NBUF while the DMAs of tiles k+1, k+2 are in flight.
-  // Waits are COUNTED (vmcnt counts loads, DMAs and stores in issue order): before tile k at least the DMAs
-  // of tile k+1 (NDMA ops) are younger than tile k's, so vmcnt(NDMA) retires tile k's patch without
-  // draining the prefetch; raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
+  // Waits are COUNTED.  vmcnt counts loads, DMAs and stores in issue order; per tile every wave issues
+  // exactly NDMA DMAs and NST stores (out-of-range ones are buffer ops with an OOB offset: issued, counted,
+  // dropped by the range check), so the ops younger than tile j's DMAs are known exactly:
+  //   stores(j-2) + DMA(j+1) + stores(j-1)  ->  vmcnt(2*NST + NDMA) retires tile j's patch while the next
+  //   patch and 32 stores stay in flight.  Raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
+  constexpr int NST = 4 * C::PXT * 2;            // stores per wave per tile: 4 channel groups x PXT x 2 dst halves
+  static_assert(2 * NST + C::NDMA <= 63, "vmcnt range");
 #pragma unroll
   for (int d = 0; d < C::NBUF - 1; ++d)
     if (t_begin + d < t_end) dma_a(t_begin + d, d);
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int k = tile - t_begin;
     const int cur = k % C::NBUF;
-    if (tile + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool next_in_flight = tile + 1 < t_end;
+    if (k >= 2) {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST + C::NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
+    } else if (k == 1) {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + C::NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    } else {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
 
@@ -918,30 +931,38 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       }
     }
 
-    // ---- epilogue for this tile
+    // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped)
     const int n = tile / tiles_img, r = tile - n * tiles_img;
     const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
+    __amdgpu_buffer_rsrc_t drs[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const DViewW D = P.dst[q];
+      const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
+      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
+                                                 D.p ? (int)dimg : 0, 0x00020000);
+    }
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
       const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
       const int fy = ty0 + (m >> 4), fx = tx0 + (m & 15);
-      if (fy < P.H && fx < P.W) {
+      const bool pix_ok = fy < P.H && fx < P.W;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          int co = cg * C::ROWS + wco * 32 + 8 * g + 4 * hh;
-          float v[4];
+      for (int g = 0; g < 4; ++g) {
+        const int co = cg * C::ROWS + wco * 32 + 8 * g + 4 * hh;
+        bf16x4 rr;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[pt][4 * g + j];
-          const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
-          if (co >= P.dst_split) co -= P.dst_split;
+        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)acc[pt][4 * g + j];
+        const u32x2 bits = __builtin_bit_cast(u32x2, rr);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                 // one store per destination view; the other one is OOB
+          const DViewW D = P.dst[q];
+          const int cq = q == 0 ? co : co - P.dst_split;
+          const bool mine = (q == 0) == (co < P.dst_split);
           const int y = fy - D.oy, x = fx - D.ox;
-          if (y >= 0 && y < D.H && x >= 0 && x < D.W) {
-            T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
-            bf16x4 rr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)v[j];
-            *reinterpret_cast<bf16x4*>(o) = rr;
-          }
+          const bool ok = mine && pix_ok && D.p && y >= 0 && y < D.H && x >= 0 && x < D.W;
+          const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + cq) * 2) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(bits, drs[q], vo, 0, 0);
         }
       }
     }
