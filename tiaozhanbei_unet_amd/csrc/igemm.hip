@@ -761,8 +761,10 @@ int32_t launch3(const IgemmParams& P, int kclass, hipStream_t s) {
     attr_done = true;
   }
   if constexpr (sizeof(T) == 2 && BN == 128 && KG == 4) {
-    const char* var = getenv("UNET_CONV_VAR");               // tuning hook: "1" = 16x16x32 MFMA variant
-    if (var && var[0] == '1') {
+    // default: the 16x16x32 MFMA variant (up to 7 % faster in interleaved A/B runs: the chip holds a
+    // higher clock on that shape); UNET_CONV_VAR=0 selects the 32x32x16 kernel (tuning hook)
+    const char* var = getenv("UNET_CONV_VAR");
+    if (!(var && var[0] == '0')) {
       using CM = Cfg3M<T, BN, KG>;
       auto km = conv3m16_kernel<T, BN, KG>;
       static bool attr_m = false;

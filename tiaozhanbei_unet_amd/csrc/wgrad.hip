@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
     if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
     const char* sR = smem + buf * C::BUF;
     const char* sC = sR + C::R_BYTES;
-#pragma unroll 1
+#pragma unroll 4
     for (int ty = 0; ty < C::TH; ++ty) {
       const int rrow = ty * C::TW + kq;
       const int rp = rrow * 128 + ((r_piece ^ r_swz) << 4) + r_sub;
