@@ -277,3 +277,32 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 4
     assert rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
+
+
+def test_nonsquare_config_shapes():
+    """BASELINE configs[3]/[4] shapes: 512x512 and the non-square 1408x512 KolektorSDD crop (H != W, both
+    divisible by 16).  A scaled-down 176x64 crop is checked against the CPU oracle in fp32; the full-size
+    crops run fwd+bwd in bf16 and are checked through size-independent properties (finite, range, BN stats)."""
+    import tiaozhanbei_unet_amd as P
+    state = W.make_state(W.state_spec("anomaly_unet", 3, 1, False), 0)
+    x = W.make_input("ns:x", (1, 3, 176, 64))
+    m, _ = make_model(("anomaly_unet", 3, 1, False), "fp32")
+    m.train()
+    with torch.no_grad():
+        r, a = m(x.to(DEV))
+        r_ref, a_ref = O.anomaly_unet_forward(state, x, True)
+    assert maxabs(r, r_ref) < 1e-3 and maxabs(a, a_ref) < 1e-3
+    for shape in ((2, 3, 1408, 512), (2, 3, 512, 512)):
+        m, _ = make_model(("anomaly_unet", 3, 1, False), "bf16")
+        m.train()
+        xb = torch.randn(*shape, device=DEV)
+        mask = (torch.rand(shape[0], 1, *shape[2:], device=DEV) < 0.02).float()
+        recon, amap = m(xb)
+        assert recon.shape == shape and amap.shape == (shape[0], 1) + shape[2:]
+        loss = P.CombinedLoss()(recon, amap, xb, mask)["total_loss"]
+        loss.backward()
+        assert bool(torch.isfinite(loss)) and 0.0 <= float(recon.min()) and float(recon.max()) <= 1.0
+        g = m.inc.double_conv[0].weight.grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        del m, recon, amap, loss
+        torch.cuda.empty_cache()
