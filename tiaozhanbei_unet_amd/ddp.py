@@ -33,6 +33,7 @@ class GradientExchange:
         self._count: List[int] = []
         self._handles = []
         self._hooks = []
+        self._events = {}
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL reduces with AVG in-kernel; gloo needs sum + scale
         self._build(bucket_bytes)
@@ -80,12 +81,22 @@ class GradientExchange:
         bi, view = self._slots[p]
         view.copy_(p.grad)
         p.grad = view                       # the optimiser reads the reduced bucket slice
+        if p.is_cuda:
+            # gradients of one bucket may be produced on different streams (the two decoder branches):
+            # remember where each slice was written so that the collective waits for all of them
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events.setdefault(bi, []).append(ev)
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi: int) -> None:
         flat = self.buckets[bi]
+        if flat.is_cuda:
+            cur = torch.cuda.current_stream(flat.device)
+            for ev in self._events.pop(bi, []):
+                cur.wait_event(ev)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._handles.append((bi, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
 

@@ -166,6 +166,16 @@ def _pack_cache(model):
     return cache
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def _encoder(m, x):
     x1 = m.inc(x)
     x2 = m.down1(x1)
@@ -234,10 +244,21 @@ class AnomalyUNet(_HipBlock):
         y = getattr(self, f"up4_{branch}")(y, x1)
         return getattr(self, f"outc_{branch}")(y, sigmoid=True)
 
+    two_streams = True     # run the two independent decoders on two HIP streams (their kernels fill each
+                           # other's ramp-up / tail; autograd replays each branch's backward on its own stream)
+
     def forward(self, x):
         ops._require_cuda(x)
         _pack_cache(self)
         feats = _encoder(self, x)
+        if not self.two_streams:
+            return self._decode(feats, "recon"), self._decode(feats, "seg")
+        main = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        side.wait_stream(main)                       # encoder features are ready
+        with torch.cuda.stream(side):
+            anomaly_map = self._decode(feats, "seg")
         reconstruction = self._decode(feats, "recon")
-        anomaly_map = self._decode(feats, "seg")
+        main.wait_stream(side)
+        anomaly_map.record_stream(main)
         return reconstruction, anomaly_map

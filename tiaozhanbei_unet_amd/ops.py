@@ -60,8 +60,9 @@ _workspaces = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch arena per device; stream-ordered reuse (one compute stream)."""
-    key = (device.type, device.index)
+    """Grow-only scratch arena per (device, stream): reuse is stream-ordered, so every compute stream has
+    its own arena (the two decoders of AnomalyUNet run on two streams)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
