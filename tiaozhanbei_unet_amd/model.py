@@ -16,6 +16,8 @@ statistics and fp32 master parameters).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -244,7 +246,7 @@ class AnomalyUNet(_HipBlock):
         y = getattr(self, f"up4_{branch}")(y, x1)
         return getattr(self, f"outc_{branch}")(y, sigmoid=True)
 
-    two_streams = True     # run the two independent decoders on two HIP streams (their kernels fill each
+    two_streams = os.environ.get("UNET_TWO_STREAMS", "1") != "0"   # run the two independent decoders on two HIP streams (their kernels fill each
                            # other's ramp-up / tail; autograd replays each branch's backward on its own stream)
 
     def forward(self, x):
