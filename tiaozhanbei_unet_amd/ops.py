@@ -57,6 +57,17 @@ def _as_nhwc(t: torch.Tensor, dtype) -> torch.Tensor:
 
 
 _workspaces = {}
+_helpers = {}
+WGRAD_SIDE_STREAM = __import__("os").environ.get("UNET_WGRAD_STREAM", "1") != "0"
+
+
+def _helper_stream(device, cur):
+    """One helper stream per compute stream (weight gradients run beside data gradients)."""
+    key = (device.index, cur.cuda_stream)
+    if key not in _helpers:
+        _helpers[key] = torch.cuda.Stream(device=device)
+    return _helpers[key]
+
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -290,12 +301,29 @@ class ConvBnRelu(torch.autograd.Function):
                                      _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         dw = None
+        wgrad_done = None
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight, dtype=torch.float32)
-            need = lib.unet_conv3x3_wgrad_workspace(n, h, w, ctot, co)
-            ws = _workspace(need, dev)
-            L.check(lib.unet_conv3x3_wgrad(dt, n, h, w, src, _ptr(dy), co, _ptr(dw), ci, _ptr(ws), ws.numel(), st),
-                    "unet_conv3x3_wgrad")
+            # the weight gradient only depends on dy and the saved input: it runs on a helper stream, next to
+            # the data gradient (their ramp-up / tail phases overlap); joined before this node returns
+            cur = torch.cuda.current_stream(dev)
+            helper = _helper_stream(dev, cur) if WGRAD_SIDE_STREAM else None
+            if helper is not None:
+                helper.wait_stream(cur)
+                torch.cuda.set_stream(helper)
+            try:
+                dw = torch.empty_like(weight, dtype=torch.float32)
+                need = lib.unet_conv3x3_wgrad_workspace(n, h, w, ctot, co)
+                ws2 = _workspace(need, dev)
+                L.check(lib.unet_conv3x3_wgrad(dt, n, h, w, src, _ptr(dy), co, _ptr(dw), ci, _ptr(ws2), ws2.numel(),
+                                               _stream()), "unet_conv3x3_wgrad")
+                if helper is not None:
+                    wgrad_done = torch.cuda.Event()
+                    wgrad_done.record(helper)
+                    dw.record_stream(cur)
+                    dy.record_stream(helper)
+            finally:
+                if helper is not None:
+                    torch.cuda.set_stream(cur)
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wp = packed(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
@@ -306,6 +334,8 @@ class ConvBnRelu(torch.autograd.Function):
             ddst = _views([(dx0, 0, 0), None if x1 is None else (dx1, oy, ox)])
             L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 0, L.K_CONV_DGRAD, st),
                     "unet_conv3x3(dgrad)")
+        if wgrad_done is not None:
+            torch.cuda.current_stream(dev).wait_event(wgrad_done)
         return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None
 
 
