@@ -107,6 +107,16 @@ int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_
                      const void* w_packed, int32_t c_out, const unet_view dst[2], int32_t dst_split,
                      int32_t accumulate, int32_t kclass, void* stream);
 
+/* The forward convolution of DoubleConv fused with the BatchNorm batch statistics (src/model.py:14-15,
+ * 17-18): y = conv(concat(src)) AND per-channel partial sums (sum, sum of squares of the stored y) written
+ * by the conv epilogue through wavefront reductions -- or, for kernel variants without that epilogue, by one
+ * extra streaming pass.  partial: fp32 [parts][2][c_out], capacity unet_conv3x3_stats_max_parts() parts;
+ * *n_parts receives the number written.  Feed them to unet_bn_finalize_partials(). */
+size_t unet_conv3x3_stats_max_parts(int32_t n, int32_t h, int32_t w);
+int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                           const void* w_packed, int32_t c_out, void* y, float* partial, int32_t* n_parts,
+                           void* stream);
+
 /* dW[co][ci][3][3] (fp32, OIHW) = sum over pixels of dY (x) shifted X; split-K over pixel
  * tiles with fp32 partial slabs in `workspace`, reduced in a fixed order (deterministic).
  * (autograd of nn.Conv2d, reached from total_loss.backward() at src/train_utils.py:132) */
@@ -137,6 +147,11 @@ int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pixels, int32_
                             const float* beta, float* running_mean, float* running_var, float momentum,
                             float eps, float* save_mean, float* save_istd, float* scale, float* shift,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* same outputs as unet_bn_train_stats, from partial sums [n_parts][2][c] (ordered fp64 reduction). */
+int32_t unet_bn_finalize_partials(const float* partial, int32_t n_parts, int64_t pixels, int32_t c,
+                                  const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* save_mean,
+                                  float* save_istd, float* scale, float* shift, void* stream);
 /* eval: scale/shift from the running statistics. */
 int32_t unet_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, void* stream);

@@ -402,3 +402,32 @@ def test_batched_weight_pack_matches_single_packs(hip, dtype):
         assert got is not None
         want = ops.pack_weight(wd, mode, rows, k, dtype)
         assert torch.equal(got.float().cpu(), want.float().cpu()), f"mode {mode}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 40), (2, 128, 128, 16, 24), (1, 128, 64, 9, 20), (3, 256, 128, 8, 8)],
+                         ids=str)
+def test_conv3x3_fused_bn_statistics(hip, dtype, case):
+    """unet_conv3x3_stats: the conv epilogue's wavefront-reduced partial sums (weight-stationary kernel, 16x16x32
+    kernel) and the streaming fallback all add up to the per-channel sum / sum of squares of the STORED y."""
+    L, ops = hip
+    n, ci, co, h, w = case
+    x = rnd(f"sx{case}", (n, ci, h, w))
+    wt = rnd(f"sw{case}", (co, ci, 3, 3)) * (1.0 / (3 * ci ** 0.5))
+    xd = nhwc(x, dtype)
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wt.to(dev()), L.PACK_CONV_FWD, co, ci, dtype)
+    cap = L.lib().unet_conv3x3_stats_max_parts(n, h, w)
+    part = torch.full((cap, 2, co), float("nan"), device=dev())
+    nparts = C.c_int32(0)
+    L.check(L.lib().unet_conv3x3_stats(ops._DT[dtype], n, h, w, views(L, [(xd, 0, 0), None]), p(wp), co, p(y), p(part),
+                                       C.byref(nparts), st()), "conv+stats")
+    assert 0 < nparts.value <= cap
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), padding=1)
+    check(y, ref, dtype, "conv output")
+    ys = y.float()
+    sums = part[:nparts.value].double().sum(0).cpu()
+    assert bool(torch.isfinite(sums).all())
+    want_s, want_q = ys.double().sum((0, 2, 3)).cpu(), (ys.double() ** 2).sum((0, 2, 3)).cpu()
+    assert float((sums[0] - want_s).abs().max()) < 1e-3 * max(1.0, float(want_s.abs().max()))
+    assert float((sums[1] - want_q).abs().max()) < 1e-3 * max(1.0, float(want_q.abs().max()))

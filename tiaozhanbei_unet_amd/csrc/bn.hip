@@ -322,6 +322,33 @@ int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, fl
   return unet_check_launch("colsum_finalize_kernel");
 }
 
+int32_t unet_internal_bn_partials(int dtype, const void* y, int64_t pixels, int C, float* part, int* n_parts,
+                                  hipStream_t s) {
+  UNET_REQUIRE(C % 64 == 0, UNET_ERR_UNSUPPORTED, "bn partials: channels %d not a multiple of 64", C);
+  const RedPlan pl = red_plan(pixels, C);
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  *n_parts = pl.nparts;
+  return dtype == UNET_BF16
+             ? launch_reduce<bf16_t, 0>(y, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, part, pl, s)
+             : launch_reduce<float, 0>(y, nullptr, pixels, C, nullptr, nullptr, nullptr, nullptr, part, pl, s);
+}
+
+extern "C" int32_t unet_bn_finalize_partials(const float* partial, int32_t n_parts, int64_t pixels, int32_t c,
+                                             const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, float momentum, float eps, float* save_mean,
+                                             float* save_istd, float* scale, float* shift, void* stream) {
+  UNET_REQUIRE(partial && gamma && beta && save_mean && save_istd && scale && shift, UNET_ERR_BAD_ARG,
+               "unet_bn_finalize_partials: null pointer");
+  UNET_REQUIRE(n_parts > 0 && pixels > 0 && c > 0 && c % FC == 0, UNET_ERR_BAD_ARG, "unet_bn_finalize_partials: dims");
+  UNET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), UNET_ERR_BAD_ARG,
+               "unet_bn_finalize_partials: running_mean/var must both be given or both NULL");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / FC), dim3(256), 0, s, partial, n_parts, c, (double)pixels,
+                     gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale, shift);
+  return unet_check_launch("bn_finalize_train_kernel");
+}
+
 extern "C" int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pixels, int32_t c,
                                        const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, float momentum, float eps, float* save_mean,

@@ -42,6 +42,10 @@ struct ProfScope {
 int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, float* out, float* ws,
                               size_t ws_bytes, hipStream_t s);
 
+// BatchNorm partial sums [parts][2][C] of y[pixels][C] by one streaming pass (bn.hip); parts <= 1024
+int32_t unet_internal_bn_partials(int dtype, const void* y, int64_t pixels, int C, float* part, int* n_parts,
+                                  hipStream_t s);
+
 // ---- element traits ----------------------------------------------------------------------
 template <typename T> struct ET;
 template <> struct ET<float> {

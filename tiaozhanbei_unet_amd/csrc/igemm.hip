@@ -43,6 +43,7 @@ struct IgemmParams {
   int imul, gtaps;  // input position = frame*imul + gather tap (convT dgrad: 2, 4)
   int omul, nZ;     // output position = frame*omul + z tap     (convT fwd:   2, 4)
   int zdiv;         // > 0: GEMM row = z*zdiv + co (convT fwd as one GEMM with 4*Cout rows)
+  float* stats;     // != NULL: per-block BatchNorm partials [part][2][Cout] written by the epilogue
   int tilesX, tilesY, nCo;
 };
 
@@ -723,6 +724,11 @@ __global__ __launch_bounds__(256, 2) void conv3m16_kernel(const IgemmParams P) {
   if (c < nchunks) chunk_body(c, std::integral_constant<int, 0>{});
 
   // ---- epilogue: D of 16x16x32: col = lane&15 (pixel), rows (lane>>4)*4 + reg (4 consecutive channels)
+  float bs[4][4], bq[4][4];            // BatchNorm partials of this lane: [ct][reg] over its pixels
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
 #pragma unroll
   for (int pt = 0; pt < PT16; ++pt) {
     const int fy = ty0 + wpx * PT16 + pt, fx = tx0 + l15;
@@ -747,19 +753,62 @@ __global__ __launch_bounds__(256, 2) void conv3m16_kernel(const IgemmParams P) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = (bf16_t)v[j];
       *reinterpret_cast<bf16x4*>(o) = r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {              // statistics of the value as STORED (bf16-rounded)
+        const float q = (float)r[j];
+        bs[ct][j] += q;
+        bq[ct][j] = fmaf(q, q, bq[ct][j]);
+      }
+    }
+  }
+  if (P.stats) {
+    // wavefront reduction over the 16 pixel lanes of each channel group, then the two pixel-waves through LDS
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bs[ct][j] += __shfl_xor(bs[ct][j], m);
+          bq[ct][j] += __shfl_xor(bq[ct][j], m);
+        }
+    __syncthreads();                               // all MFMA operand reads of the tile are done: reuse LDS
+    float* red = reinterpret_cast<float*>(smem);   // [WPX][2][BN]
+    if (l15 == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cl = wco * 64 + ct * 16 + kb * 4 + j;
+          red[(wpx * 2 + 0) * BN + cl] = bs[ct][j];
+          red[(wpx * 2 + 1) * BN + cl] = bq[ct][j];
+        }
+    }
+    __syncthreads();
+    const int part = (n * P.tilesY + tyi) * P.tilesX + txi;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int q = i / BN, cl = i - q * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int wp = 0; wp < C::WPX; ++wp) t += red[(wp * 2 + q) * BN + cl];
+      P.stats[((size_t)part * 2 + q) * P.Cout + co0 + cl] = t;
     }
   }
 }
 
 template <typename T, int BN, int KG>
-int32_t launch3(const IgemmParams& P, int kclass, hipStream_t s) {
+int32_t launch3(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_parts) {
   using C = Cfg3<T, BN, KG>;
+  IgemmParams P = Pin;
   auto kern = conv3_kernel<T, BN, KG>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
+  const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
+  UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "conv3: grid of %lld blocks", blocks);
+  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   if constexpr (sizeof(T) == 2 && BN == 128 && KG == 4) {
     // default: the 16x16x32 MFMA variant (up to 7 % faster in interleaved A/B runs: the chip holds a
     // higher clock on that shape); UNET_CONV_VAR=0 selects the 32x32x16 kernel (tuning hook)
@@ -772,21 +821,17 @@ int32_t launch3(const IgemmParams& P, int kclass, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(km), hipFuncAttributeMaxDynamicSharedMemorySize, CM::LDS);
         attr_m = true;
       }
-      const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
-      const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
+      if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;   // epilogue writes the BN partials
       ProfScope prof(kclass, flops, s);
       hipLaunchKernelGGL(km, dim3((unsigned)blocks), dim3(256), CM::LDS, s, P);
       return unet_check_launch("conv3m16_kernel");
     }
   }
-  const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
-  UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "conv3: grid of %lld blocks", blocks);
-  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
+  P.stats = nullptr;
   ProfScope prof(kclass, flops, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
   return unet_check_launch("conv3_kernel");
 }
-
 
 // ------------------------------------------------------------------------------------------------------
 // conv3_ws_kernel: weight-stationary 3x3 convolution for the wide-spatial / narrow-channel layers
@@ -830,7 +875,10 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   const int total_tiles = P.N * tiles_img;
   const int t_begin = tr * tiles_per_block;
   const int t_end = min(t_begin + tiles_per_block, total_tiles);
-  if (t_begin >= t_end) return;
+  if (t_begin >= t_end) {
+    if (P.stats && tid < 128) P.stats[((size_t)tr * 2 + (tid >> 6)) * P.Cout + cg * CfgWS::ROWS + (tid & 63)] = 0.f;
+    return;
+  }
 
   // ---- this wave's weights -> registers: A fragment (tap, kg) = W[co_lane][tap][16*kg + 8*hh .. +7]
   bf16x8 wreg[36];
@@ -892,6 +940,9 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   // dropped by the range check), so the ops younger than tile j's DMAs are known exactly:
   //   stores(j-2) + DMA(j+1) + stores(j-1)  ->  vmcnt(2*NST + NDMA) retires tile j's patch while the next
   //   patch and 32 stores stay in flight.  Raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
+  float bs[16], bq[16];                  // BatchNorm partials of this lane over all its tiles: [4*g + j]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { bs[i] = 0.f; bq[i] = 0.f; }
   constexpr int NST = 4 * C::PXT * 2;            // stores per wave per tile: 4 channel groups x PXT x 2 dst halves
   static_assert(2 * NST + C::NDMA <= 63, "vmcnt range");
 #pragma unroll
@@ -956,6 +1007,14 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)acc[pt][4 * g + j];
         const u32x2 bits = __builtin_bit_cast(u32x2, rr);
+        if (pix_ok) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {            // statistics of the value as STORED (bf16-rounded)
+            const float q = (float)rr[j];
+            bs[4 * g + j] += q;
+            bq[4 * g + j] = fmaf(q, q, bq[4 * g + j]);
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                 // one store per destination view; the other one is OOB
           const DViewW D = P.dst[q];
@@ -969,9 +1028,37 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       }
     }
   }
+  if (P.stats) {
+    // wavefront reduction over the 32 pixel lanes, then the four pixel-waves through LDS (ring is drained)
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        bs[i] += __shfl_xor(bs[i], m);
+        bq[i] += __shfl_xor(bq[i], m);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 wpx][2][64]
+    if (l31 == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int cl = wco * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
+        red[(wpx * 2 + 0) * 64 + cl] = bs[i];
+        red[(wpx * 2 + 1) * 64 + cl] = bq[i];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int q = tid >> 6, cl = tid & 63;
+      const float t = (red[(0 * 2 + q) * 64 + cl] + red[(1 * 2 + q) * 64 + cl]) +
+                      (red[(2 * 2 + q) * 64 + cl] + red[(3 * 2 + q) * 64 + cl]);
+      P.stats[((size_t)tr * 2 + q) * P.Cout + cg * C::ROWS + cl] = t;
+    }
+  }
 }
 
-int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s) {
+int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   using C = CfgWS;
   auto kern = conv3_ws_kernel;
   static bool attr_done = false;
@@ -988,14 +1075,17 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s) {
   const long long ranges8 = cdiv64(cdiv64(tiles, tpb), 8) * 8;      // tile ranges, padded to a multiple of 8 (XCDs)
   const long long blocks = ranges8 * nCg;
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
+  if (P.stats && stat_parts) *stat_parts = (int)ranges8;
   ProfScope prof(kclass, flops, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P, tpb);
   return unet_check_launch("conv3_ws_kernel");
 }
 
 template <typename T, int TAPS, int BN, int KG>
-int32_t launch(const IgemmParams& P, int kclass, hipStream_t s) {
+int32_t launch(const IgemmParams& Pin, int kclass, hipStream_t s) {
   using C = Cfg<T, TAPS, BN, KG>;
+  IgemmParams P = Pin;
+  P.stats = nullptr;
   auto kern = igemm_kernel<T, TAPS, BN, KG>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1011,7 +1101,8 @@ int32_t launch(const IgemmParams& P, int kclass, hipStream_t s) {
 }
 
 template <typename T, int TAPS>
-int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s) {
+int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nullptr) {
+  if (stat_parts) *stat_parts = 0;
   constexpr int CK4 = 4 * ET<T>::KGC;
   UNET_REQUIRE(P.Cout % 64 == 0, UNET_ERR_UNSUPPORTED, "igemm: c_out %d is not a multiple of 64", P.Cout);
   UNET_REQUIRE(P.Ctot % ET<T>::KGC == 0, UNET_ERR_UNSUPPORTED, "igemm: input channels %d not a multiple of %d",
@@ -1031,15 +1122,15 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s) {
     // 64-channel inputs: weight-stationary streaming kernel (impl "2" forces it off)
     const bool ws_ok = P.Ctot == 64 && P.src[1].C == 0 && !P.accumulate &&
                        !(impl_env && (impl_env[0] == '0' || impl_env[0] == '2'));
-    if (ws_ok) return launch_ws(P, kclass, s);
+    if (ws_ok) return launch_ws(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9) {
     if (!use3 || P.Ctot < 2 * CK4) {
       if (big) return k4 ? launch<T, TAPS, 128, 4>(P, kclass, s) : launch<T, TAPS, 128, 1>(P, kclass, s);
       return k4 ? launch<T, TAPS, 64, 4>(P, kclass, s) : launch<T, TAPS, 64, 1>(P, kclass, s);
     }
-    if (big) return k4 ? launch3<T, 128, 4>(P, kclass, s) : launch3<T, 128, 1>(P, kclass, s);
-    return k4 ? launch3<T, 64, 4>(P, kclass, s) : launch3<T, 64, 1>(P, kclass, s);
+    if (big) return k4 ? launch3<T, 128, 4>(P, kclass, s, stat_parts) : launch3<T, 128, 1>(P, kclass, s, stat_parts);
+    return k4 ? launch3<T, 64, 4>(P, kclass, s, stat_parts) : launch3<T, 64, 1>(P, kclass, s, stat_parts);
   } else {
     if (big) return k4 ? launch<T, TAPS, 128, 4>(P, kclass, s) : launch<T, TAPS, 128, 1>(P, kclass, s);
     return k4 ? launch<T, TAPS, 64, 4>(P, kclass, s) : launch<T, TAPS, 64, 1>(P, kclass, s);
@@ -1079,6 +1170,43 @@ extern "C" int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, 
   if (dtype == UNET_F32) return dispatch<float, 9>(P, kclass, s);
   unet_set_error("unet_conv3x3: dtype %d", dtype);
   return UNET_ERR_BAD_ARG;
+}
+
+extern "C" size_t unet_conv3x3_stats_max_parts(int32_t n, int32_t h, int32_t w) {
+  const size_t tiles = (size_t)n * cdiv(h, TH) * cdiv(w, TW);
+  return tiles > 1024 ? tiles : 1024;
+}
+
+extern "C" int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                                      const void* w_packed, int32_t c_out, void* y, float* partial,
+                                      int32_t* n_parts, void* stream) {
+  UNET_REQUIRE(src && w_packed && src[0].ptr && y && partial && n_parts, UNET_ERR_BAD_ARG,
+               "unet_conv3x3_stats: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0 && c_out > 0, UNET_ERR_BAD_ARG, "unet_conv3x3_stats: bad dims");
+  IgemmParams P{};
+  P.src[0] = in_view(src[0]);
+  P.src[1] = src[1].ptr ? in_view(src[1]) : DView{nullptr, 0, 0, 0, 0, 0};
+  P.dst[0] = DViewW{(char*)y, c_out, h, w, 0, 0};
+  P.dst[1] = DViewW{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = P.src[0].C + P.src[1].C;
+  P.Cout = c_out;
+  P.wK = P.Ctot;
+  P.w = (const char*)w_packed;
+  P.dst_split = c_out;
+  P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
+  P.stats = partial;
+  hipStream_t s = (hipStream_t)stream;
+  int parts = 0;
+  int32_t rc;
+  if (dtype == UNET_BF16) rc = dispatch<bf16_t, 9>(P, UNET_K_CONV_FWD, s, &parts);
+  else if (dtype == UNET_F32) rc = dispatch<float, 9>(P, UNET_K_CONV_FWD, s, &parts);
+  else { unet_set_error("unet_conv3x3_stats: dtype %d", dtype); return UNET_ERR_BAD_ARG; }
+  if (rc) return rc;
+  if (parts == 0)   // this kernel variant has no fused statistics: one streaming pass over y instead
+    rc = unet_internal_bn_partials(dtype, y, (int64_t)n * h * w, c_out, partial, &parts, s);
+  *n_parts = parts;
+  return rc;
 }
 
 extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x,

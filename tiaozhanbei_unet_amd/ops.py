@@ -259,17 +259,23 @@ class ConvBnRelu(torch.autograd.Function):
         wp = packed(weight, L.PACK_CONV_FWD, co, ctot, dtype)
         y = _nhwc_empty(n, co, h, w, dtype, dev)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
-        dst = _views([(y, 0, 0), None])
-        L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
         pixels = n * h * w
         coef = torch.empty((4, co), dtype=torch.float32, device=dev)   # mean, istd, scale, shift
         if training:
-            ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
-            L.check(lib.unet_bn_train_stats(dt, _ptr(y), pixels, co, _ptr(gamma), _ptr(beta),
-                                            _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
-                                            _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]),
-                                            _ptr(ws), ws.numel(), st), "unet_bn_train_stats")
+            # conv + BatchNorm batch statistics in one call: the conv epilogue reduces sum / sum-of-squares per
+            # channel with wavefront shuffles (or one extra streaming pass for kernels without that epilogue)
+            cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+            part = _workspace(cap * 2 * co * 4, dev)
+            nparts = C.c_int32(0)
+            L.check(lib.unet_conv3x3_stats(dt, n, h, w, src, _ptr(wp), co, _ptr(y), _ptr(part), C.byref(nparts), st),
+                    "unet_conv3x3_stats")
+            L.check(lib.unet_bn_finalize_partials(_ptr(part), nparts.value, pixels, co, _ptr(gamma), _ptr(beta),
+                                                  _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
+                                                  _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
+                    "unet_bn_finalize_partials")
         else:
+            dst = _views([(y, 0, 0), None])
+            L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
             L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                             BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
         a = _nhwc_empty(n, co, h, w, dtype, dev)
