@@ -1195,7 +1195,8 @@ extern "C" int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32
   P.w = (const char*)w_packed;
   P.dst_split = c_out;
   P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
-  P.stats = partial;
+  const char* fs = getenv("UNET_FUSED_STATS");            // tuning hook: "0" = always the streaming pass
+  P.stats = (fs && fs[0] == '0') ? nullptr : partial;
   hipStream_t s = (hipStream_t)stream;
   int parts = 0;
   int32_t rc;
