@@ -1041,6 +1041,189 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   return unet_check_launch("conv3_ws_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// convt_ws_kernel<CIN>: weight-stationary streaming kernel for the wide transposed convolutions (up3: 256->128,
+// up4: 128->64; AI ~ 85-170 FLOP/B => HBM-bound).  ConvTranspose2d(k2,s2) is ONE GEMM [pixels x CIN] x
+// [CIN x 4*Cout] whose rows scatter to the 2x2 sub-positions.  Eight waves each keep 32 of 256 GEMM rows x CIN
+// of weights in registers (CIN/16 MFMA A-fragments); 128-pixel input tiles (no halo) stream through an LDS ring
+// filled by LDS-DMA; per tile and wave CIN/16 x 4 MFMAs, 16 buffer stores (8 B, bias added), one barrier.
+template <int CIN>
+struct CfgTW {
+  static constexpr int TP = 128;                               // pixels per tile
+  static constexpr int ROWP = CIN / 8 + 1;                      // 16-byte pieces per LDS row (one pad piece)
+  static constexpr int RSTR = ROWP * 16;                        // 272 / 528 B: conflict-free ds_read_b128
+  static constexpr int PIECES = TP * ROWP;
+  static constexpr int NWAVE = 8;
+  static constexpr int NINSTR = (PIECES + 63) / 64;
+  static constexpr int NDMA = (NINSTR + NWAVE - 1) / NWAVE;
+  static constexpr int A_BYTES = NINSTR * 1024;
+  static constexpr int NBUF = (CIN <= 128) ? 3 : 2;
+  static constexpr int LDS = NBUF * A_BYTES + 1024;
+  static constexpr int PXT = TP / 32;                           // 4 MFMA pixel tiles per wave
+  static constexpr int KGN = CIN / 16;
+  static constexpr int NST = 4 * PXT;                           // stores per wave per tile
+};
+
+struct ConvTParams {
+  const char* x; char* y; const char* w; const float* bias;
+  int N, H, W, Cout;      // input spatial dims; output is [N][2H][2W][Cout]
+  int tiles, tiles_per_block;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(512, 1) void convt_ws_kernel(const ConvTParams P) {
+  using C = CfgTW<CIN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int rows_total = 4 * P.Cout;
+  const int nCg = rows_total / 256;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cg = slot % nCg, tr = (slot / nCg) * 8 + xcd;
+  const int row_lane = cg * 256 + wave * 32 + l31;              // GEMM row = z*Cout + co
+  const int t_begin = tr * P.tiles_per_block;
+  const int t_end = min(t_begin + P.tiles_per_block, P.tiles);
+  if (t_begin >= t_end) return;
+
+  bf16x8 wreg[C::KGN];
+  {
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(P.w);
+#pragma unroll
+    for (int kg = 0; kg < C::KGN; ++kg)
+      wreg[kg] = *reinterpret_cast<const bf16x8*>(wp + (size_t)row_lane * CIN + kg * 16 + hh * 8);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // retire here, not inside the tile loop
+  }
+
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const long long total_px = (long long)P.N * P.H * P.W;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.x, (short)0, (int)std::min<long long>(total_px * CIN * 2, 0x7FFFFFFFLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.y, (short)0, (int)std::min<long long>(total_px * 4 * P.Cout * 2, 0x7FFFFFFFLL), 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  // DMA descriptors: piece q = idx*64 + lane -> (pixel row, piece in row); pad piece / beyond the tile = OOB
+  int d_row[C::NDMA], d_off[C::NDMA];
+#pragma unroll
+  for (int j = 0; j < C::NDMA; ++j) {
+    const int q = (j * C::NWAVE + wave) * 64 + lane;
+    const int row = q / C::ROWP, pc = q - row * C::ROWP;
+    d_row[j] = (row < C::TP && pc < CIN / 8) ? row : -1;
+    d_off[j] = pc * 16;
+  }
+  auto dma = [&](int tile, int buf) {
+    const long long p0 = (long long)tile * C::TP;
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+      const int idx = j * C::NWAVE + wave;
+      const long long px = p0 + d_row[j];
+      const bool ok = d_row[j] >= 0 && px < total_px;
+      const unsigned vo = ok ? (unsigned)(px * (CIN * 2) + d_off[j]) : OOB;
+      char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)dst, 16, vo, 0, 0, 0);
+    }
+  };
+
+  float bias4[4][4];                      // bias of this lane's 16 rows: [g][j] -> row 8g + 4hh + j
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = cg * 256 + wave * 32 + 8 * g + 4 * hh + j;
+      bias4[g][j] = P.bias ? P.bias[r % P.Cout] : 0.f;
+    }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  static_assert(2 * C::NST + C::NDMA * (C::NBUF - 1) <= 63, "vmcnt range");
+#pragma unroll
+  for (int d = 0; d < C::NBUF - 1; ++d)
+    if (t_begin + d < t_end) dma(t_begin + d, d);
+  const int HW = P.H * P.W;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int k = tile - t_begin;
+    const int cur = k % C::NBUF;
+    // ops younger than tile `tile`'s DMAs: the DMAs of the (NBUF-2) later tiles still in flight + the stores of
+    // the previous tiles issued after them (exact counts; see conv3_ws_kernel)
+    const int later = min(C::NBUF - 2, t_end - 1 - tile);      // later tiles whose DMAs are already issued
+    const int st_tiles = min(k, C::NBUF - 1);                  // previous tiles whose stores are younger
+    if constexpr (C::NBUF == 3) {
+      // issue order: ... DMA(t) | stores(t-2) | DMA(t+1) | stores(t-1) |  -> younger than DMA(t):
+      if (later >= 1) {
+        if (st_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NST + C::NDMA) : "memory");
+        else if (st_tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST + C::NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
+      } else {
+        if (st_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NST) : "memory");
+        else if (st_tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      // NBUF == 2: DMA(t) was issued during tile t-1, before stores(t-1)
+      if (st_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (tile + C::NBUF - 1 < t_end) dma(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
+
+    f32x16 acc[C::PXT];
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
+    const char* pb = smem + cur * C::A_BYTES + l31 * C::RSTR + hh * 16;
+#pragma unroll
+    for (int kg = 0; kg < C::KGN; ++kg)
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + kg * 32);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], fb, acc[pt], 0, 0, 0);
+      }
+
+    // ---- epilogue: scatter to (2y+zk, 2x+zl); exactly NST buffer stores per wave
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt) {
+      const long long px = (long long)tile * C::TP + pt * 32 + l31;
+      const bool ok = px < total_px;
+      const int n = (int)(px / HW), rem = (int)(px - (long long)n * HW);
+      const int y = rem / P.W, x = rem - y * P.W;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = cg * 256 + wave * 32 + 8 * g + 4 * hh;
+        const int z = r / P.Cout, co = r - z * P.Cout;
+        bf16x4 rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)(acc[pt][4 * g + j] + bias4[g][j]);
+        const long long opix = ((long long)n * 2 * P.H + 2 * y + (z >> 1)) * (2 * P.W) + 2 * x + (z & 1);
+        const unsigned vo = ok ? (unsigned)((opix * P.Cout + co) * 2) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), yrs, vo, 0, 0);
+      }
+    }
+  }
+}
+
+template <int CIN>
+int32_t launch_convt_ws(ConvTParams P, hipStream_t s) {
+  using C = CfgTW<CIN>;
+  auto kern = convt_ws_kernel<CIN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const long long total_px = (long long)P.N * P.H * P.W;
+  P.tiles = (int)cdiv64(total_px, C::TP);
+  const int nCg = 4 * P.Cout / 256;
+  int tpb = (int)cdiv64((long long)P.tiles * nCg, 256);
+  if (tpb < 2) tpb = 2;
+  P.tiles_per_block = tpb;
+  const long long ranges8 = cdiv64(cdiv64(P.tiles, tpb), 8) * 8;
+  const double flops = 2.0 * total_px * 4.0 * P.Cout * CIN;
+  ProfScope prof(UNET_K_CONVT_FWD, flops, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ranges8 * nCg)), dim3(512), C::LDS, s, P);
+  return unet_check_launch("convt_ws_kernel");
+}
+
 template <typename T, int TAPS, int BN, int KG>
 int32_t launch(const IgemmParams& Pin, int kclass, hipStream_t s) {
   using C = Cfg<T, TAPS, BN, KG>;
@@ -1175,6 +1358,15 @@ extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_
                                      int32_t c_out, void* stream) {
   UNET_REQUIRE(x && w_packed && y, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: null pointer");
   UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: bad dims");
+  {
+    const char* tw = getenv("UNET_CONVT_IMPL");               // tuning hook: "0" = generic igemm path
+    const long long out_bytes = (long long)n * 4 * h * w * c_out * 2;
+    if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_in == 128 || c_in == 256) && out_bytes < 0x7FFFFFFFLL &&
+        !(tw && tw[0] == '0')) {
+      ConvTParams T{(const char*)x, (char*)y, (const char*)w_packed, bias, n, h, w, c_out, 0, 0};
+      return c_in == 128 ? launch_convt_ws<128>(T, (hipStream_t)stream) : launch_convt_ws<256>(T, (hipStream_t)stream);
+    }
+  }
   IgemmParams P{};
   P.src[0] = DView{(const char*)x, c_in, h, w, 0, 0};
   P.dst[0] = DViewW{(char*)y, c_out, 2 * h, 2 * w, 0, 0};
