@@ -83,32 +83,39 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
   }
 }
 
-// ordered fp64 sum of the block partials: block = 16 channels x 16 row-lanes
+// ordered fp64 sum of the block partials: block = FC channels x FL row-lanes (FL*FC = 256)
 constexpr int FL = 16, FC = 16;
-__device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][FL][FC],
-                                 double& a, double& b) {
+template <int TL, int TC>
+__device__ inline void sum_parts_t(const float* part, int nparts, int C, int c, int rl, double (&red)[2][TL][TC],
+                                   double& a, double& b) {
   double s0 = 0.0, s1 = 0.0;
-  for (int k = rl; k < nparts; k += FL) {
+  for (int k = rl; k < nparts; k += TL) {
     s0 += (double)part[((size_t)k * 2 + 0) * C + c];
     s1 += (double)part[((size_t)k * 2 + 1) * C + c];
   }
-  red[0][rl][c % FC] = s0;
-  red[1][rl][c % FC] = s1;
+  red[0][rl][c % TC] = s0;
+  red[1][rl][c % TC] = s1;
   __syncthreads();
   a = 0.0; b = 0.0;
 #pragma unroll
-  for (int i = 0; i < FL; ++i) { a += red[0][i][c % FC]; b += red[1][i][c % FC]; }
+  for (int i = 0; i < TL; ++i) { a += red[0][i][c % TC]; b += red[1][i][c % TC]; }
+}
+__device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][FL][FC],
+                                 double& a, double& b) {
+  sum_parts_t<FL, FC>(part, nparts, C, c, rl, red, a, b);
 }
 
+// TL x TC = 256: (16,16) for few partials, (64,4) when a conv epilogue produced thousands of them
+template <int TL, int TC>
 __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
     const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* __restrict__ save_mean, float* __restrict__ save_istd, float* __restrict__ scale,
     float* __restrict__ shift) {
-  __shared__ double red[2][FL][FC];
-  const int c = blockIdx.x * FC + (threadIdx.x % FC), rl = threadIdx.x / FC;
+  __shared__ double red[2][TL][TC];
+  const int c = blockIdx.x * TC + (threadIdx.x % TC), rl = threadIdx.x / TC;
   double s, ss;
-  sum_parts(part, nparts, C, c, rl, red, s, ss);
+  sum_parts_t<TL, TC>(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
   const double mean = s / count;
   double var = ss / count - mean * mean;
@@ -344,8 +351,14 @@ extern "C" int32_t unet_bn_finalize_partials(const float* partial, int32_t n_par
                "unet_bn_finalize_partials: running_mean/var must both be given or both NULL");
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s);
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / FC), dim3(256), 0, s, partial, n_parts, c, (double)pixels,
-                     gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale, shift);
+  if (n_parts >= 1024)
+    hipLaunchKernelGGL((bn_finalize_train_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, partial, n_parts, c,
+                       (double)pixels, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd,
+                       scale, shift);
+  else
+    hipLaunchKernelGGL((bn_finalize_train_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, partial, n_parts, c,
+                       (double)pixels, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd,
+                       scale, shift);
   return unet_check_launch("bn_finalize_train_kernel");
 }
 
@@ -370,8 +383,9 @@ extern "C" int32_t unet_bn_train_stats(int32_t dtype, const void* y, int64_t pix
                    ? launch_reduce<bf16_t, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s)
                    : launch_reduce<float, 0>(y, nullptr, pixels, c, nullptr, nullptr, nullptr, nullptr, part, pl, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, (double)pixels,
-                     gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale, shift);
+  hipLaunchKernelGGL((bn_finalize_train_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c,
+                     (double)pixels, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd, scale,
+                     shift);
   return unet_check_launch("bn_finalize_train_kernel");
 }
 

@@ -12,101 +12,127 @@ namespace {
 
 constexpr int MAXCO = 8;
 
-template <typename T, int TPP>
+template <typename T, int TPP, int CO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long long pixels, long long hw,
                                                        int Cin, const float* __restrict__ w,
-                                                       const float* __restrict__ b, int CO, int sigm,
+                                                       const float* __restrict__ b, int sigm,
                                                        float* __restrict__ out) {
   constexpr int PIECE = ET<T>::PIECE;
-  __shared__ float sw[MAXCO * 128];   // host checks c_out <= 8, c_in <= 128
-  for (int i = threadIdx.x; i < CO * Cin; i += 256) sw[i] = w[i];
-  __syncthreads();
+  constexpr int U = 4;                  // pixels in flight per thread (memory-level parallelism)
   const int g = threadIdx.x % TPP;
+  float wr[CO][PIECE];                  // this lane's slice of the CO filters, in registers
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) wr[co][j] = w[co * Cin + g * PIECE + j];
   const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
   const long long nslots = (long long)gridDim.x * 256 / TPP;
   // every lane of a wave runs the same number of iterations (shuffles need all lanes)
-  const long long iters = cdiv64(pixels, nslots);
+  const long long iters = cdiv64(pixels, nslots * U);
   for (long long it = 0; it < iters; ++it) {
-    const long long p = slot + it * nslots;
-    const bool ok = p < pixels;
-    float v[PIECE];
+    float v[U][PIECE];
+    long long p[U];
 #pragma unroll
-    for (int j = 0; j < PIECE; ++j) v[j] = 0.f;
-    if (ok) Vec<T>::load(x + p * Cin + g * PIECE, v);
-    float acc[MAXCO];
+    for (int u = 0; u < U; ++u) {
+      p[u] = slot + (it * U + u) * nslots;
 #pragma unroll
-    for (int co = 0; co < MAXCO; ++co) {
-      acc[co] = 0.f;
-      if (co < CO) {
-#pragma unroll
-        for (int j = 0; j < PIECE; ++j) acc[co] = fmaf(v[j], sw[co * Cin + g * PIECE + j], acc[co]);
-      }
+      for (int j = 0; j < PIECE; ++j) v[u][j] = 0.f;
+      if (p[u] < pixels) Vec<T>::load(x + p[u] * Cin + g * PIECE, v[u]);
     }
 #pragma unroll
-    for (int m = 1; m < TPP; m <<= 1)
+    for (int u = 0; u < U; ++u) {
+      float acc[CO];
 #pragma unroll
-      for (int co = 0; co < MAXCO; ++co) acc[co] += __shfl_xor(acc[co], m);
-    if (ok && g < CO) {
-      float r = 0.f;
+      for (int co = 0; co < CO; ++co) {
+        acc[co] = 0.f;
 #pragma unroll
-      for (int co = 0; co < MAXCO; ++co) if (co == g) r = acc[co];
-      r += b[g];
-      if (sigm) r = 1.f / (1.f + expf(-r));
-      const long long n = p / hw, q = p - n * hw;
-      out[(n * CO + g) * hw + q] = r;
+        for (int j = 0; j < PIECE; ++j) acc[co] = fmaf(v[u][j], wr[co][j], acc[co]);
+      }
+#pragma unroll
+      for (int m = 1; m < TPP; m <<= 1)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] += __shfl_xor(acc[co], m);
+      if (p[u] < pixels && g < CO) {
+        float r = 0.f;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) if (co == g) r = acc[co];
+        r += b[g];
+        if (sigm) r = 1.f / (1.f + expf(-r));
+        const long long n = p[u] / hw, q = p[u] - n * hw;
+        out[(n * CO + g) * hw + q] = r;
+      }
     }
   }
 }
 
-template <typename T, int TPP>
+template <typename T, int TPP, int CO>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ out,
                                                        const float* __restrict__ dout, long long pixels,
-                                                       long long hw, int Cin, const float* __restrict__ w, int CO,
+                                                       long long hw, int Cin, const float* __restrict__ w,
                                                        int sigm, T* __restrict__ dx, float* __restrict__ part) {
   constexpr int PIECE = ET<T>::PIECE;
-  __shared__ float sw[MAXCO * 128];
+  constexpr int U = 4;
   __shared__ float red[4][MAXCO * 129];
-  for (int i = threadIdx.x; i < CO * Cin; i += 256) sw[i] = w[i];
-  __syncthreads();
   const int g = threadIdx.x % TPP;
+  float wr[CO][PIECE];
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) wr[co][j] = w[co * Cin + g * PIECE + j];
   const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
   const long long nslots = (long long)gridDim.x * 256 / TPP;
-  const long long iters = cdiv64(pixels, nslots);
-  float dwacc[MAXCO][PIECE], dbacc[MAXCO];
+  const long long iters = cdiv64(pixels, nslots * U);
+  float dwacc[CO][PIECE], dbacc[CO];
 #pragma unroll
-  for (int co = 0; co < MAXCO; ++co) {
+  for (int co = 0; co < CO; ++co) {
     dbacc[co] = 0.f;
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) dwacc[co][j] = 0.f;
   }
   for (long long it = 0; it < iters; ++it) {
-    const long long p = slot + it * nslots;
-    if (p >= pixels) continue;
-    const long long n = p / hw, q = p - n * hw;
-    float v[PIECE], d[PIECE];
-    Vec<T>::load(x + p * Cin + g * PIECE, v);
+    float v[U][PIECE], dl[U][CO];
+    long long p[U];
 #pragma unroll
-    for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      p[u] = slot + (it * U + u) * nslots;
 #pragma unroll
-    for (int co = 0; co < MAXCO; ++co) {
-      if (co < CO) {
-        float dl = dout[(n * CO + co) * hw + q];
-        if (sigm) { const float o = out[(n * CO + co) * hw + q]; dl *= o * (1.f - o); }
-        if (g == 0) dbacc[co] += dl;
+      for (int j = 0; j < PIECE; ++j) v[u][j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < PIECE; ++j) {
-          d[j] = fmaf(dl, sw[co * Cin + g * PIECE + j], d[j]);
-          dwacc[co][j] = fmaf(dl, v[j], dwacc[co][j]);
+      for (int co = 0; co < CO; ++co) dl[u][co] = 0.f;
+      if (p[u] < pixels) {
+        Vec<T>::load(x + p[u] * Cin + g * PIECE, v[u]);
+        const long long n = p[u] / hw, q = p[u] - n * hw;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          float d = dout[(n * CO + co) * hw + q];
+          if (sigm) { const float o = out[(n * CO + co) * hw + q]; d *= o * (1.f - o); }
+          dl[u][co] = d;
         }
       }
     }
-    Vec<T>::store(dx + p * Cin + g * PIECE, d);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (p[u] >= pixels) continue;
+      float d[PIECE];
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        if (g == 0) dbacc[co] += dl[u][co];
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) {
+          d[j] = fmaf(dl[u][co], wr[co][j], d[j]);
+          dwacc[co][j] = fmaf(dl[u][co], v[u][j], dwacc[co][j]);
+        }
+      }
+      Vec<T>::store(dx + p[u] * Cin + g * PIECE, d);
+    }
   }
   // lanes with equal g (stride TPP) hold partials of the same channels: combine across the wave
 #pragma unroll
   for (int m = TPP; m < 64; m <<= 1) {
 #pragma unroll
-    for (int co = 0; co < MAXCO; ++co) {
+    for (int co = 0; co < CO; ++co) {
       dbacc[co] += __shfl_xor(dbacc[co], m);
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) dwacc[co][j] += __shfl_xor(dwacc[co][j], m);
@@ -116,12 +142,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   const int stride = Cin + 1;
   if (lane < TPP) {
 #pragma unroll
-    for (int co = 0; co < MAXCO; ++co) {
-      if (co < CO) {
+    for (int co = 0; co < CO; ++co) {
 #pragma unroll
-        for (int j = 0; j < PIECE; ++j) red[wave][co * stride + lane * PIECE + j] = dwacc[co][j];
-        if (lane == 0) red[wave][co * stride + Cin] = dbacc[co];
-      }
+      for (int j = 0; j < PIECE; ++j) red[wave][co * stride + lane * PIECE + j] = dwacc[co][j];
+      if (lane == 0) red[wave][co * stride + Cin] = dbacc[co];
     }
   }
   __syncthreads();
@@ -161,15 +185,23 @@ int tpp_of(int c_in) { return c_in / ET<T>::PIECE; }
 
 }  // namespace
 
-#define HEAD_TPP_SWITCH(T, tpp, CALL)                      \
-  switch (tpp) {                                           \
-    case 4: { constexpr int TPP = 4; CALL; } break;        \
-    case 8: { constexpr int TPP = 8; CALL; } break;        \
-    case 16: { constexpr int TPP = 16; CALL; } break;      \
-    case 32: { constexpr int TPP = 32; CALL; } break;      \
-    default:                                               \
-      unet_set_error("head: c_in %d unsupported", c_in);   \
-      return UNET_ERR_UNSUPPORTED;                         \
+#define HEAD_CO_SWITCH(...)                                  \
+  switch (c_out) {                                          \
+    case 1: { constexpr int CO = 1; __VA_ARGS__; } break;          \
+    case 2: { constexpr int CO = 2; __VA_ARGS__; } break;          \
+    case 3: { constexpr int CO = 3; __VA_ARGS__; } break;          \
+    case 4: { constexpr int CO = 4; __VA_ARGS__; } break;          \
+    default: { constexpr int CO = 8; __VA_ARGS__; } break;         \
+  }
+#define HEAD_TPP_SWITCH(T, tpp, ...)                        \
+  switch (tpp) {                                            \
+    case 4: { constexpr int TPP = 4; HEAD_CO_SWITCH(__VA_ARGS__); } break;   \
+    case 8: { constexpr int TPP = 8; HEAD_CO_SWITCH(__VA_ARGS__); } break;   \
+    case 16: { constexpr int TPP = 16; HEAD_CO_SWITCH(__VA_ARGS__); } break; \
+    case 32: { constexpr int TPP = 32; HEAD_CO_SWITCH(__VA_ARGS__); } break; \
+    default:                                                \
+      unet_set_error("head: c_in %d unsupported", c_in);    \
+      return UNET_ERR_UNSUPPORTED;                          \
   }
 
 extern "C" int32_t unet_head_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c_in,
@@ -185,12 +217,12 @@ extern "C" int32_t unet_head_fwd(int32_t dtype, const void* x, int32_t n, int32_
   ProfScope prof(UNET_K_HEAD, 2.0 * pixels * c_in * c_out, s);
   if (dtype == UNET_BF16) {
     const int tpp = tpp_of<bf16_t>(c_in);
-    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_fwd_kernel<bf16_t, TPP>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
-                    (const bf16_t*)x, pixels, hw, c_in, weight, bias, c_out, sigmoid, out));
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_fwd_kernel<bf16_t, TPP, CO>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
+                    (const bf16_t*)x, pixels, hw, c_in, weight, bias, sigmoid, out));
   } else {
     const int tpp = tpp_of<float>(c_in);
-    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_fwd_kernel<float, TPP>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
-                    (const float*)x, pixels, hw, c_in, weight, bias, c_out, sigmoid, out));
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_fwd_kernel<float, TPP, CO>), dim3(head_blocks(pixels, TPP)), dim3(256), 0, s,
+                    (const float*)x, pixels, hw, c_in, weight, bias, sigmoid, out));
   }
   return unet_check_launch("head_fwd_kernel");
 }
@@ -218,13 +250,13 @@ extern "C" int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out,
   if (dtype == UNET_BF16) {
     const int tpp = tpp_of<bf16_t>(c_in);
     nb = head_blocks(pixels, tpp);
-    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP>), dim3(nb), dim3(256), 0, s,
-                    (const bf16_t*)x, out, dout, pixels, hw, c_in, weight, c_out, sigmoid, (bf16_t*)dx, (float*)workspace));
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP, CO>), dim3(nb), dim3(256), 0, s,
+                    (const bf16_t*)x, out, dout, pixels, hw, c_in, weight, sigmoid, (bf16_t*)dx, (float*)workspace));
   } else {
     const int tpp = tpp_of<float>(c_in);
     nb = head_blocks(pixels, tpp);
-    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_bwd_kernel<float, TPP>), dim3(nb), dim3(256), 0, s,
-                    (const float*)x, out, dout, pixels, hw, c_in, weight, c_out, sigmoid, (float*)dx, (float*)workspace));
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_bwd_kernel<float, TPP, CO>), dim3(nb), dim3(256), 0, s,
+                    (const float*)x, out, dout, pixels, hw, c_in, weight, sigmoid, (float*)dx, (float*)workspace));
   }
   int32_t rc = unet_check_launch("head_bwd_kernel");
   if (rc) return rc;
