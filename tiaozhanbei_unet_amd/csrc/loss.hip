@@ -56,13 +56,15 @@ __global__ __launch_bounds__(256) void mse_focal_kernel(const float* __restrict_
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
 }
 
-__global__ void mse_focal_finalize_kernel(const float* __restrict__ part, int nblocks, double nr, double na,
-                                          float* __restrict__ losses) {
-  if (threadIdx.x < 2) {
-    double s = 0.0;
-    for (int k = 0; k < nblocks; ++k) s += (double)part[2 * k + threadIdx.x];
-    losses[threadIdx.x] = (float)(s / (threadIdx.x == 0 ? nr : na));
-  }
+// 2 waves: wave q sums the block partials of loss q (64 lanes, then a fixed-order butterfly) in fp64
+__global__ __launch_bounds__(128) void mse_focal_finalize_kernel(const float* __restrict__ part, int nblocks,
+                                                                 double nr, double na, float* __restrict__ losses) {
+  const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int k = lane; k < nblocks; k += 64) s += (double)part[2 * k + q];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) losses[q] = (float)(s / (q == 0 ? nr : na));
 }
 
 // ------------------------------------------------------------------------------------ SSIM
@@ -241,7 +243,7 @@ extern "C" int32_t unet_loss_mse_focal(const float* recon, const float* image, i
                      (long long)n_amap, alpha, gamma, d_recon, d_amap, (float*)workspace);
   int32_t rc = unet_check_launch("mse_focal_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(mse_focal_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nb,
+  hipLaunchKernelGGL(mse_focal_finalize_kernel, dim3(1), dim3(128), 0, s, (const float*)workspace, nb,
                      (double)n_recon, (double)n_amap, losses);
   return unet_check_launch("mse_focal_finalize_kernel");
 }
