@@ -150,6 +150,9 @@ def main():
     # ---- roofline of the dominant kernel class: hipEvent brackets inside libunet_hip, 2 extra steps
     roof = None
     # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
+    # The two decoder branches normally run on two HIP streams; for these two steps they run on ONE stream so
+    # that an event bracket times its kernel alone (concurrent kernels would inflate each other's brackets).
+    model.two_streams = False
     if rank == 0:
         ops.prof_enable(True)
     for _ in range(2):
@@ -167,6 +170,7 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
+                    "measured": "hipEvent brackets on the launch stream, 2 single-stream steps after the timed region",
                     "per_class_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in prof.items() if v["launches"]},
                     "per_class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
                                          for k, v in mfma.items()}}
