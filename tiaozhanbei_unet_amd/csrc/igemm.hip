@@ -1224,6 +1224,149 @@ int32_t launch_convt_ws(ConvTParams P, hipStream_t s) {
   return unet_check_launch("convt_ws_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// convt_dgrad_ws_kernel<COUT>: data gradient of the wide transposed convolutions, same streaming design as
+// convt_ws_kernel.  dx[p][ci] = sum_{z,co} dy[(2y+zk, 2x+zl)][co] * w[ci][z][co]: GEMM rows = CIN = 2*COUT,
+// K = 4*COUT gathered from the 2x2 sub-positions of dy (the gather happens in the DMA's per-lane source address,
+// the LDS row of a pixel is its 4*COUT K-vector).  Weights (32 rows x K per wave) live in registers.
+template <int COUT>
+struct CfgTD {
+  static constexpr int CIN = 2 * COUT, K = 4 * COUT;
+  static constexpr int TP = (COUT <= 64) ? 128 : 64;
+  static constexpr int ROWP = K / 8 + 1;
+  static constexpr int RSTR = ROWP * 16;
+  static constexpr int PIECES = TP * ROWP;
+  static constexpr int NWAVE = 8;
+  static constexpr int NINSTR = (PIECES + 63) / 64;
+  static constexpr int NDMA = (NINSTR + NWAVE - 1) / NWAVE;
+  static constexpr int A_BYTES = NINSTR * 1024;
+  static constexpr int NBUF = 2;
+  static constexpr int LDS = NBUF * A_BYTES + 1024;
+  static constexpr int RW = CIN / 32;                           // waves along rows (4 or 8)
+  static constexpr int PW = NWAVE / RW;                         // waves along pixels (2 or 1)
+  static constexpr int PXT = TP / PW / 32;                      // MFMA pixel tiles per wave (2)
+  static constexpr int KGN = K / 16;
+  static constexpr int NST = 4 * PXT;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParams P) {
+  using C = CfgTD<COUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wr = wave % C::RW, wp = wave / C::RW;
+  const int row_lane = wr * 32 + l31;
+  const int t_begin = blockIdx.x * P.tiles_per_block;
+  const int t_end = min(t_begin + P.tiles_per_block, P.tiles);
+  if (t_begin >= t_end) return;
+
+  bf16x8 wreg[C::KGN];
+  {
+    const bf16_t* wpk = reinterpret_cast<const bf16_t*>(P.w);
+#pragma unroll
+    for (int kg = 0; kg < C::KGN; ++kg)
+      wreg[kg] = *reinterpret_cast<const bf16x8*>(wpk + (size_t)row_lane * C::K + kg * 16 + hh * 8);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const long long total_px = (long long)P.N * P.H * P.W;       // dx pixels (half-resolution grid)
+  const int HW = P.H * P.W;
+  // P.x = dy [N][2H][2W][COUT], P.y = dx [N][H][W][CIN]
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.x, (short)0, (int)std::min<long long>(total_px * 4 * COUT * 2, 0x7FFFFFFFLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.y, (short)0, (int)std::min<long long>(total_px * C::CIN * 2, 0x7FFFFFFFLL), 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  int d_row[C::NDMA], d_z[C::NDMA], d_c[C::NDMA];
+#pragma unroll
+  for (int j = 0; j < C::NDMA; ++j) {
+    const int q = (j * C::NWAVE + wave) * 64 + lane;
+    const int row = q / C::ROWP, pc = q - row * C::ROWP;
+    d_row[j] = (row < C::TP && pc < C::K / 8) ? row : -1;
+    d_z[j] = pc / (COUT / 8);
+    d_c[j] = (pc % (COUT / 8)) * 16;
+  }
+  auto dma = [&](int tile, int buf) {
+    const long long p0 = (long long)tile * C::TP;
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+      const int idx = j * C::NWAVE + wave;
+      const long long px = p0 + d_row[j];
+      const bool ok = d_row[j] >= 0 && px < total_px;
+      const int n = (int)(px / HW), rem = (int)(px - (long long)n * HW);
+      const int y = rem / P.W, x = rem - y * P.W;
+      const long long ipix = ((long long)n * 2 * P.H + 2 * y + (d_z[j] >> 1)) * (2 * P.W) + 2 * x + (d_z[j] & 1);
+      const unsigned vo = ok ? (unsigned)(ipix * (COUT * 2) + d_c[j]) : OOB;
+      char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)dst, 16, vo, 0, 0, 0);
+    }
+  };
+
+  dma(t_begin, 0);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int k = tile - t_begin;
+    const int cur = k & 1;
+    // DMA(t) was issued during tile t-1 BEFORE stores(t-1): exactly NST younger ops
+    if (k >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + 1 < t_end) dma(tile + 1, cur ^ 1);
+
+    f32x16 acc[C::PXT];
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
+    const char* pb = smem + cur * C::A_BYTES + (wp * C::PXT * 32 + l31) * C::RSTR + hh * 16;
+#pragma unroll
+    for (int kg = 0; kg < C::KGN; ++kg)
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + kg * 32);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], fb, acc[pt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt) {
+      const long long px = (long long)tile * C::TP + (wp * C::PXT + pt) * 32 + l31;
+      const bool ok = px < total_px;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = wr * 32 + 8 * g + 4 * hh;
+        bf16x4 rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)acc[pt][4 * g + j];
+        const unsigned vo = ok ? (unsigned)((px * C::CIN + r) * 2) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), yrs, vo, 0, 0);
+      }
+    }
+  }
+}
+
+template <int COUT>
+int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s) {
+  using C = CfgTD<COUT>;
+  auto kern = convt_dgrad_ws_kernel<COUT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const long long total_px = (long long)P.N * P.H * P.W;
+  P.tiles = (int)cdiv64(total_px, C::TP);
+  int tpb = (int)cdiv64(P.tiles, 256);
+  if (tpb < 2) tpb = 2;
+  P.tiles_per_block = tpb;
+  const long long blocks = cdiv64(P.tiles, tpb);
+  const double flops = 2.0 * total_px * 4.0 * COUT * C::CIN;
+  ProfScope prof(UNET_K_CONVT_DGRAD, flops, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
+  return unet_check_launch("convt_dgrad_ws_kernel");
+}
+
 template <typename T, int TAPS, int BN, int KG>
 int32_t launch(const IgemmParams& Pin, int kclass, hipStream_t s) {
   using C = Cfg<T, TAPS, BN, KG>;
@@ -1390,6 +1533,16 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
                                        void* stream) {
   UNET_REQUIRE(dy && w_packed && dx, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: null pointer");
   UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: bad dims");
+  {
+    const char* tw = getenv("UNET_CONVT_IMPL");               // tuning hook: "0" = generic igemm path
+    const long long in_bytes = (long long)n * 4 * h * w * c_out * 2;
+    if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_out == 64 || c_out == 128) && in_bytes < 0x7FFFFFFFLL &&
+        !(tw && tw[0] == '0')) {
+      ConvTParams T{(const char*)dy, (char*)dx, (const char*)w_packed, nullptr, n, h, w, c_out, 0, 0};
+      return c_out == 64 ? launch_convt_dgrad_ws<64>(T, (hipStream_t)stream)
+                         : launch_convt_dgrad_ws<128>(T, (hipStream_t)stream);
+    }
+  }
   IgemmParams P{};
   P.src[0] = DView{(const char*)dy, c_out, 2 * h, 2 * w, 0, 0};
   P.dst[0] = DViewW{(char*)dx, c_in, h, w, 0, 0};

@@ -60,7 +60,20 @@ def main():
         y = ops._nhwc_empty(n, co, 2 * h, 2 * w, dt, dev)
         wp = ops.pack_weight(wt, L.PACK_CONVT_FWD, co, ci, dt)
         flops = 2.0 * n * h * w * co * ci * 4
-        run = lambda: L.check(lib.unet_convt2x2_fwd(ops._DT[dt], n, h, w, p(x), ci, p(wp), p(b), p(y), co, st), "convt")
+        wpd = ops.pack_weight(wt, L.PACK_CONVT_DGRAD, ci, co, dt)
+        gy = torch.randn(n, co, 2 * h, 2 * w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+        dx = ops._nhwc_empty(n, ci, h, w, dt, dev)
+        dw = torch.empty_like(wt)
+        db = torch.empty(co, device=dev)
+        need = lib.unet_convt2x2_wgrad_workspace(n, h, w, ci, co)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        if a.op == "fwd":
+            run = lambda: L.check(lib.unet_convt2x2_fwd(ops._DT[dt], n, h, w, p(x), ci, p(wp), p(b), p(y), co, st), "convt")
+        elif a.op == "dgrad":
+            run = lambda: L.check(lib.unet_convt2x2_dgrad(ops._DT[dt], n, h, w, p(gy), co, p(wpd), p(dx), ci, st), "convt dgrad")
+        else:
+            run = lambda: L.check(lib.unet_convt2x2_wgrad(ops._DT[dt], n, h, w, p(x), ci, p(gy), co, p(dw), p(db),
+                                                          p(ws), need, st), "convt wgrad")
     variants = a.ab.split(",") if a.ab else [None]
     best = {v: 1e9 for v in variants}
     for rnd in range(4 if a.ab else 1):
@@ -77,7 +90,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
-    if a.ab and a.kind == "conv":
+    if a.ab:
         outs = {}
         for v in variants:
             os.environ[a.abvar] = v
