@@ -254,6 +254,7 @@ __device__ inline bf16x8 tr_frag2(const char* base, int off0, int off1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <bool REUSE>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) {
   using C = WDma;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -284,6 +285,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
   const int r_piece = (wr * 64 + chb) >> 4, r_sub = (wr * 64 + chb) & 15;
   const int c_piece = (wc * 64 + chb) >> 4, c_sub = (wc * 64 + chb) & 15;
   const int r_swz = (((kq >> 1) & 1) << 2);                    // row = ty*16 + kq (+4): bit 1 of kq
+  int c_base[2][3];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx)
+      c_base[par][sx] = (kq + sx) * 128 + ((c_piece ^ (((((kq + sx) >> 1) ^ par) & 1) << 2)) << 4) + c_sub;
 
   // ---- DMA descriptors: instruction ii = j*4 + wave; < R_INSTR -> dY tile, else X patch
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -351,17 +358,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
     if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
     const char* sR = smem + buf * C::BUF;
     const char* sC = sR + C::R_BYTES;
-#pragma unroll 4
-    for (int ty = 0; ty < C::TH; ++ty) {
-      const int rrow = ty * C::TW + kq;
-      const int rp = rrow * 128 + ((r_piece ^ r_swz) << 4) + r_sub;
-      const bf16x8 fa = tr_frag2(sR, rp, rp + 4 * 128);
+    if constexpr (REUSE) {
+      // the X fragment of (tile row ty, tap row r, tap column s) is the fragment of (ty+1, r-1, s): keep the
+      // three live patch rows x three column shifts in registers and fetch only the new patch row per ty
+      // (30 + 8 instead of 72 + 8 transposed fragment reads per tile: the LDS array was the limiter)
+      // patch row stride 18 is even, so the swizzle bit of row prow*18 + kq + sx is ((kq+sx)>>1 ^ prow) & 1:
+      // two lane addresses per column shift (even / odd patch row), the row itself is an immediate offset
+      auto load_c = [&](int prow, int sx) {
+        const int cp = c_base[prow & 1][sx] + prow * (C::HW * 128);
+        return tr_frag2(sC, cp, cp + 4 * 128);                  // rows +4: same swizzle bit
+      };
+      bf16x8 fb[3][3];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int crow = (ty + tap / 3) * C::HW + kq + tap % 3;
-        const int cp = crow * 128 + ((c_piece ^ (((crow >> 1) & 1) << 2)) << 4) + c_sub;
-        const bf16x8 fb = tr_frag2(sC, cp, cp + 4 * 128);       // rows +4: same swizzle bit
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+      for (int sx = 0; sx < 3; ++sx) { fb[0][sx] = load_c(0, sx); fb[1][sx] = load_c(1, sx); }
+#pragma unroll
+      for (int ty = 0; ty < C::TH; ++ty) {
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) fb[(ty + 2) % 3][sx] = load_c(ty + 2, sx);
+        const int rrow = ty * C::TW + kq;
+        const int rp = rrow * 128 + ((r_piece ^ r_swz) << 4) + r_sub;
+        const bf16x8 fa = tr_frag2(sR, rp, rp + 4 * 128);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[(ty + tap / 3) % 3][tap % 3], acc[tap], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ty = 0; ty < C::TH; ++ty) {
+        const int rrow = ty * C::TW + kq;
+        const int rp = rrow * 128 + ((r_piece ^ r_swz) << 4) + r_sub;
+        const bf16x8 fa = tr_frag2(sR, rp, rp + 4 * 128);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int crow = (ty + tap / 3) * C::HW + kq + tap % 3;
+          const int cp = crow * 128 + ((c_piece ^ (((crow >> 1) & 1) << 2)) << 4) + c_sub;
+          const bf16x8 fb = tr_frag2(sC, cp, cp + 4 * 128);       // rows +4: same swizzle bit
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+        }
       }
     }
   }
@@ -448,11 +481,16 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
       if (!(impl && impl[0] == '0')) {
         static bool dma_attr = false;
         if (!dma_attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel),
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WDma::LDS);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, WDma::LDS);
           dma_attr = true;
         }
-        hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
+        if (impl && impl[0] == '2')                             // "2": every tap re-reads its X fragment
+          hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
+        else
+          hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
       } else {
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
       }
