@@ -100,7 +100,8 @@ int32_t unet_pack_weights_batched(const unet_pack_desc* descs, int32_t n, int32_
 /* y = conv(concat(src[0], src[1])) as an implicit GEMM on MFMA.  Output channels below
  * dst_split go to dst[0], the rest to dst[1] (dst[1].ptr may be NULL when dst_split == c_out).
  * The same entry computes the data gradient when given UNET_PACK_CONV_DGRAD weights:
- * dX = conv(dY, flipped W^T).  `accumulate` adds into dst (gradient fan-in of the skips).
+ * dX = conv(dY, flipped W^T).  `accumulate` is a bit mask: bit 0 -> dst[0] += result, bit 1 -> dst[1] += result
+ * (gradient fan-in of the skip connections: the three consumers of a skip tensor add into one buffer).
  * Requires: channel counts of each src multiples of 64 (or a single src of 8/16 for the
  * image layer), c_out multiple of 64. */
 int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
@@ -168,8 +169,9 @@ int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t p
 /* ---- MaxPool2d(2) (src/model.py:32): stride 2, floor; first maximum wins ties ---------- */
 int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c,
                           void* y, void* stream);
+/* accumulate != 0: dx += routed gradient (dx already holds the other consumers' gradient of x). */
 int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* dy, int32_t n, int32_t h, int32_t w,
-                          int32_t c, void* dx, void* stream);
+                          int32_t c, void* dx, int32_t accumulate, void* stream);
 
 /* ---- bilinear x2, align_corners=True (nn.Upsample, src/model.py:48) -------------------- */
 int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,

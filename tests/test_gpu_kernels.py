@@ -170,6 +170,13 @@ def test_conv3x3_concat_and_centre_pad_views(hip, dtype):
                                  views(L, [(d2, 0, 0), (d1, oy, ox)]), c0, 0, 1, st()), "dgrad")
     check(d2, x2q.grad, dtype, "skip gradient")
     check(d1, x1q.grad, dtype, "up-sampled gradient (cropped by the pad)")
+    # accumulate is a bit mask over the two destination views: 1 = only the skip half adds into its buffer
+    # (the in-place gradient fan-in of ops.GradSink), 2 = only the second view
+    for mask, k2, k1 in ((1, 2, 1), (2, 1, 2), (3, 2, 3)):
+        L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), c0 + c1,
+                                     views(L, [(d2, 0, 0), (d1, oy, ox)]), c0, mask, 1, st()), "dgrad acc")
+        check(d2, k2 * x2q.grad, dtype, f"skip gradient after accumulate={mask}", f32=2e-4, bf=4e-2)
+        check(d1, k1 * x1q.grad, dtype, f"up gradient after accumulate={mask}", f32=2e-4, bf=4e-2)
     dw = torch.empty(co, c0 + c1, 3, 3, device=dev())
     need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
     ws = torch.empty(need, dtype=torch.uint8, device=dev())
@@ -262,6 +269,12 @@ def test_maxpool(hip, dtype, case):
     check(y, ref, dtype, "maxpool fwd", f32=0, bf=0)
     y.backward(nhwc(gy, dtype))
     check(xd.grad, xq.grad, dtype, "maxpool bwd (first-max ties, floor)", f32=0, bf=0)
+    # accumulate: dx += routed gradient (third consumer of a skip tensor)
+    base = rnd(f"pb{case}", (n, c, h, w))
+    dx = nhwc(base, dtype).clone(memory_format=torch.channels_last)
+    L.check(L.lib().unet_maxpool2_bwd(ops._DT[dtype], p(xd.detach()), p(nhwc(gy, dtype)), n, h, w, c, p(dx), 1, st()),
+            "maxpool bwd accumulate")
+    check(dx, q(base, dtype) + xq.grad, dtype, "maxpool bwd accumulate", f32=1e-6, bf=2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)

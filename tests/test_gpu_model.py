@@ -223,6 +223,35 @@ def test_properties_at_benchmark_size():
     assert float(r.min()) >= 0 and float(r.max()) <= 1 and bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_skip_gradient_fan_in_matches_autograd_sums(precision, two_streams):
+    """ops.GradSink (the consumers of a skip tensor add their data gradients into ONE buffer inside their
+    kernels) against plain autograd accumulation (one tensor per consumer + add kernels): same parameter
+    gradients, with the decoders on one and on two HIP streams."""
+    import tiaozhanbei_unet_amd as P
+    from tiaozhanbei_unet_amd import ops
+    model, _ = make_model(("anomaly_unet", 3, 1, False), precision)
+    model.train()
+    model.two_streams = two_streams
+    x = W.make_input("fanin:x", (2, 3, 32, 48)).to(DEV)
+    tgt = W.make_input("fanin:t", (2, 3, 32, 48)).to(DEV).sigmoid()
+    grads = {}
+    try:
+        for share in (True, False):
+            ops.SHARE_SKIP_GRADS = share
+            model.zero_grad(set_to_none=True)
+            r, a = model(x)
+            ((r - tgt) ** 2).mean().add(a.mean()).backward()
+            torch.cuda.synchronize()
+            grads[share] = {k: v.grad.clone() for k, v in model.named_parameters()}
+    finally:
+        ops.SHARE_SKIP_GRADS = True
+    worst = max(l2rel(grads[True][k], grads[False][k]) for k in grads[True])
+    # same addition order (the autograd engine's), same roundings: equal up to bf16 ties in the fp32 sums
+    assert worst <= (1e-6 if precision == "fp32" else 2e-2), worst
+
+
 @pytest.mark.parametrize("model", ["anomaly_unet", "unet"])
 def test_cli_train_then_test_roundtrip(tmp_path, model):
     """BASELINE configs[0]-style plumbing (2 epochs, bs=4) through the train/test CLIs on an MVTec-layout toy

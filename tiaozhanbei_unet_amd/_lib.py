@@ -57,7 +57,7 @@ SIGNATURES = {
     "unet_bn_relu_apply": (_i, [_i, _p, _l, _i, _p, _p, _p, _p]),
     "unet_bn_relu_bwd": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "unet_maxpool2_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
-    "unet_maxpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "unet_maxpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "unet_upsample_bilinear2x_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_upsample_bilinear2x_bwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_head_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),

@@ -157,7 +157,7 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
 // gradient goes to the FIRST maximum in row-major window order; rows/cols dropped by floor get 0.
 template <typename T>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                    int N, int H, int W, int C) {
+                                    int N, int H, int W, int C, int accumulate) {
   constexpr int PIECE = ET<T>::PIECE;
   const int OH = H / 2, OW = W / 2, G = C / PIECE;
   const int WH = (H + 1) / 2, WW = (W + 1) / 2;   // windows incl. the ragged edge
@@ -188,11 +188,19 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
         const bool fd = !fa && !fb && !fc;
         ga[j] = fa ? gr[j] : 0.f; gb[j] = fb ? gr[j] : 0.f; gc[j] = fc ? gr[j] : 0.f; gd[j] = fd ? gr[j] : 0.f;
       }
+      if (accumulate) {                     // dx += routed gradient (fan-in of a skip connection)
+        Vec<T>::load(dx + base, a);
+        Vec<T>::load(dx + base + C, b);
+        Vec<T>::load(dx + base + (long long)W * C, c);
+        Vec<T>::load(dx + base + (long long)W * C + C, d);
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) { ga[j] += a[j]; gb[j] += b[j]; gc[j] += c[j]; gd[j] += d[j]; }
+      }
       Vec<T>::store(dx + base, ga);
       Vec<T>::store(dx + base + C, gb);
       Vec<T>::store(dx + base + (long long)W * C, gc);
       Vec<T>::store(dx + base + (long long)W * C + C, gd);
-    } else {
+    } else if (!accumulate) {
       // ragged edge: whatever exists of this window was not pooled
       const int y0 = 2 * oy, x0 = 2 * ox;
       for (int dyy = 0; dyy < 2; ++dyy)
@@ -392,11 +400,11 @@ extern "C" int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, in
 }
 
 extern "C" int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* dy, int32_t n, int32_t h,
-                                     int32_t w, int32_t c, void* dx, void* stream) {
+                                     int32_t w, int32_t c, void* dx, int32_t accumulate, void* stream) {
   UNET_REQUIRE(x && dy && dx, UNET_ERR_BAD_ARG, "unet_maxpool2_bwd: null pointer");
   UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_maxpool2_bwd: dims");
   EW_DISPATCH("maxpool2_bwd_kernel", maxpool2_bwd_kernel, (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * c,
-              (const T*)x, (const T*)dy, (T*)dx, n, h, w, c);
+              (const T*)x, (const T*)dy, (T*)dx, n, h, w, c, accumulate);
 }
 
 extern "C" int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,

@@ -246,13 +246,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += P.bias[co + j];
         }
+        const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
         const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
         if (co >= P.dst_split) co -= P.dst_split;
         const int y = fy * P.omul + zk - D.oy, x = fx * P.omul + zl - D.ox;
         if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
         T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
         if constexpr (sizeof(T) == 2) {
-          if (P.accumulate) {
+          if (accq) {
             bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
           for (int j = 0; j < 4; ++j) r[j] = (bf16_t)v[j];
           *reinterpret_cast<bf16x4*>(o) = r;
         } else {
-          if (P.accumulate) {
+          if (accq) {
             f32x4 old = *reinterpret_cast<const f32x4*>(o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += old[j];
@@ -506,13 +507,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const IgemmParams P) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][4 * g + j];
+        const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
         const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
         if (co >= P.dst_split) co -= P.dst_split;
         const int y = fy - D.oy, x = fx - D.ox;
         if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
         T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
         if constexpr (sizeof(T) == 2) {
-          if (P.accumulate) {
+          if (accq) {
             bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const IgemmParams P) {
           for (int j = 0; j < 4; ++j) r[j] = (bf16_t)v[j];
           *reinterpret_cast<bf16x4*>(o) = r;
         } else {
-          if (P.accumulate) {
+          if (accq) {
             f32x4 old = *reinterpret_cast<const f32x4*>(o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += old[j];
@@ -739,12 +741,13 @@ __global__ __launch_bounds__(256, 2) void conv3m16_kernel(const IgemmParams P) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
-      const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
+      const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
+        const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
       if (co >= P.dst_split) co -= P.dst_split;
       const int y = fy - D.oy, x = fx - D.ox;
       if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
       T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
-      if (P.accumulate) {
+      if (accq) {
         bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
@@ -1018,12 +1021,13 @@ __global__ __launch_bounds__(512, 1) void conv3_dma_kernel(const IgemmParams P) 
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
-      const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
+      const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
+        const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
       if (co >= P.dst_split) co -= P.dst_split;
       const int y = fy - D.oy, x = fx - D.ox;
       if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
       T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
-      if (P.accumulate) {
+      if (accq) {
         bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
@@ -1120,6 +1124,7 @@ struct CfgWS {
   static constexpr int ROWS = 64;                               // output channels per block
 };
 
+template <bool ACC>
 __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, int tiles_per_block) {
   using C = CfgWS;
   typedef bf16_t T;
@@ -1199,7 +1204,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   // dropped by the range check), so the ops younger than tile j's DMAs are known exactly:
   //   stores(j-2) + DMA(j+1) + stores(j-1)  ->  vmcnt(2*NST + NDMA) retires tile j's patch while the next
   //   patch and 32 stores stay in flight.  Raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
-  constexpr int NST = 4 * C::PXT * 2;            // stores per wave per tile: 4 channel groups x PXT x 2 dst halves
+  constexpr int NST = 2 * C::PXT * 2;            // stores per wave per tile: 2 sixteen-channel groups x PXT x 2 dst views
   static_assert(2 * NST + C::NDMA <= 63, "vmcnt range");
 #pragma unroll
   for (int d = 0; d < C::NBUF - 1; ++d)
@@ -1221,6 +1226,56 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     __builtin_amdgcn_s_barrier();
     if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
 
+    // ---- output geometry of this tile (buffer stores: an OOB offset = dropped, so the op count is static)
+    const int n = tile / tiles_img, r = tile - n * tiles_img;
+    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
+    __amdgpu_buffer_rsrc_t drs[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const DViewW D = P.dst[q];
+      const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
+      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
+                                                 D.p ? (int)dimg : 0, 0x00020000);
+    }
+    // A lane of the 32x32 accumulator owns rows 8g+4hh..+3 of pixel l31; v_permlane32_swap trades the g-odd run
+    // of the lower half-wave for the g-even run of the upper one, so every lane ends up with 8 CONSECUTIVE
+    // channels (rows 16gp + 8hh ..+7) and writes 16 bytes: half as many store instructions, 32-byte segments.
+    unsigned ovo[C::PXT][2][2];
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt) {
+      const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
+      const int fy = ty0 + (m >> 4), fx = tx0 + (m & 15);
+      const bool pix_ok = fy < P.H && fx < P.W;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int co = cg * C::ROWS + wco * 32 + 16 * gp + 8 * hh;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                 // one store per destination view; the other one is OOB
+          const DViewW D = P.dst[q];
+          const int cq = q == 0 ? co : co - P.dst_split;
+          const bool mine = (q == 0) == (co < P.dst_split);
+          const int y = fy - D.oy, x = fx - D.ox;
+          const bool ok = mine && pix_ok && D.p && y >= 0 && y < D.H && x >= 0 && x < D.W;
+          ovo[pt][gp][q] = ok ? (unsigned)(((y * D.W + x) * D.C + cq) * 2) : OOB;
+        }
+      }
+    }
+    // gradient fan-in (ACC): the old values are fetched NOW, behind the tile's 72 MFMAs (one load per output
+    // run, from whichever view owns it and has its accumulate bit set; everything else reads as 0)
+    u32x4 oldv[ACC ? C::PXT : 1][2];
+    if constexpr (ACC) {
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const bool second = ovo[pt][gp][0] == OOB;
+          const bool want = (P.accumulate >> (second ? 1 : 0)) & 1;
+          const unsigned vo = want ? (second ? ovo[pt][gp][1] : ovo[pt][gp][0]) : OOB;
+          oldv[pt][gp] = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
+                                : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
+        }
+    }
+
     f32x16 acc[C::PXT];
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt)
@@ -1241,39 +1296,34 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     }
 
     // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped)
-    const int n = tile / tiles_img, r = tile - n * tiles_img;
-    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
-    __amdgpu_buffer_rsrc_t drs[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const DViewW D = P.dst[q];
-      const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
-      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
-                                                 D.p ? (int)dimg : 0, 0x00020000);
-    }
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
-      const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
-      const int fy = ty0 + (m >> 4), fx = tx0 + (m & 15);
-      const bool pix_ok = fy < P.H && fx < P.W;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = cg * C::ROWS + wco * 32 + 8 * g + 4 * hh;
-        bf16x4 rr;
+      for (int gp = 0; gp < 2; ++gp) {
+        bf16x4 xa, xb;
+        if constexpr (ACC) {
+          // bring the old values (8 consecutive channels per lane) back to the accumulator's lane layout with the
+          // same exchange, add in fp32, round once
+          const u32x4 o = oldv[pt][gp];
+          const auto o0 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+          const auto o1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+          const bf16x4 oa = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
+          const bf16x4 ob = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)acc[pt][4 * g + j];
-        const u32x2 bits = __builtin_bit_cast(u32x2, rr);
-
+          for (int j = 0; j < 4; ++j) {
+            xa[j] = (bf16_t)(acc[pt][8 * gp + j] + (float)oa[j]);
+            xb[j] = (bf16_t)(acc[pt][8 * gp + 4 + j] + (float)ob[j]);
+          }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                 // one store per destination view; the other one is OOB
-          const DViewW D = P.dst[q];
-          const int cq = q == 0 ? co : co - P.dst_split;
-          const bool mine = (q == 0) == (co < P.dst_split);
-          const int y = fy - D.oy, x = fx - D.ox;
-          const bool ok = mine && pix_ok && D.p && y >= 0 && y < D.H && x >= 0 && x < D.W;
-          const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + cq) * 2) : OOB;
-          __builtin_amdgcn_raw_buffer_store_b64(bits, drs[q], vo, 0, 0);
+          for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)acc[pt][8 * gp + j]; xb[j] = (bf16_t)acc[pt][8 * gp + 4 + j]; }
         }
+        const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+        const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][gp][q], 0, 0);
       }
     }
   }
@@ -1281,10 +1331,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 
 int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   using C = CfgWS;
-  auto kern = conv3_ws_kernel;
+  auto kern = P.accumulate ? conv3_ws_kernel<true> : conv3_ws_kernel<false>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   P.tilesX = cdiv(P.W, C::WTW);
@@ -1668,7 +1721,7 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nu
   const bool use3 = !(impl_env && impl_env[0] == '0');
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // 64-channel inputs: weight-stationary streaming kernel (impl "2" forces it off)
-    const bool ws_ok = P.Ctot == 64 && P.src[1].C == 0 && !P.accumulate &&
+    const bool ws_ok = P.Ctot == 64 && P.src[1].C == 0 &&
                        !(impl_env && (impl_env[0] == '0' || impl_env[0] == '2'));
     if (ws_ok) return launch_ws(P, kclass, s, stat_parts);
   }

@@ -57,9 +57,32 @@ def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool):
     out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                track, bn.momentum if bn.momentum is not None else 0.1)
     if training and bn.num_batches_tracked is not None:
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+        if _deferred_counters is not None:
+            _deferred_counters.append(bn.num_batches_tracked)
+        else:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
     return out
+
+
+# Inside a whole-model forward the 46 `num_batches_tracked += 1` updates are issued as ONE multi-tensor launch.
+_deferred_counters = None
+
+
+class _BatchedCounters:
+    def __enter__(self):
+        global _deferred_counters
+        self.outer = _deferred_counters
+        _deferred_counters = []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred_counters
+        mine, _deferred_counters = _deferred_counters, self.outer
+        if mine and exc[0] is None:
+            with torch.no_grad():
+                torch._foreach_add_(mine, 1)
+        return False
 
 
 class DoubleConv(_HipBlock):
@@ -179,10 +202,11 @@ def _side_stream(device):
 
 
 def _encoder(m, x):
-    x1 = m.inc(x)
-    x2 = m.down1(x1)
-    x3 = m.down2(x2)
-    x4 = m.down3(x3)
+    # x1..x4 feed the next level AND the decoder(s): their gradients meet in one buffer (ops.GradSink)
+    x1 = ops.share_grad(m.inc(x))
+    x2 = ops.share_grad(m.down1(x1))
+    x3 = ops.share_grad(m.down2(x2))
+    x4 = ops.share_grad(m.down3(x3))
     x5 = m.down4(x4)
     return x1, x2, x3, x4, x5
 
@@ -209,12 +233,13 @@ class UNet(_HipBlock):
     def forward(self, x):
         ops._require_cuda(x)
         _pack_cache(self)
-        x1, x2, x3, x4, x5 = _encoder(self, x)
-        y = self.up1(x5, x4)
-        y = self.up2(y, x3)
-        y = self.up3(y, x2)
-        y = self.up4(y, x1)
-        return self.outc(y)
+        with _BatchedCounters():
+            x1, x2, x3, x4, x5 = _encoder(self, x)
+            y = self.up1(x5, x4)
+            y = self.up2(y, x3)
+            y = self.up3(y, x2)
+            y = self.up4(y, x1)
+            return self.outc(y)
 
 
 class AnomalyUNet(_HipBlock):
@@ -250,6 +275,10 @@ class AnomalyUNet(_HipBlock):
                            # other's ramp-up / tail; autograd replays each branch's backward on its own stream)
 
     def forward(self, x):
+        with _BatchedCounters():
+            return self._forward(x)
+
+    def _forward(self, x):
         ops._require_cuda(x)
         _pack_cache(self)
         feats = _encoder(self, x)

@@ -232,6 +232,64 @@ def packed(weight, mode, rows, k, dtype):
     return pack_weight(weight, mode, rows, k, dtype)
 
 
+# ----------------------------------------------------------------------------- gradient fan-in of the skips
+class GradSink:
+    """In-place gradient fan-in of an activation with several consumers (the skip tensors x1..x4 feed the
+    next encoder level and both decoders, /root/reference/src/model.py:190-207).
+
+    Autograd would materialise one gradient per consumer and add them with two more elementwise passes
+    (9 tensor sweeps per skip).  With a sink the first consumer to run its backward WRITES the buffer and
+    hands it to autograd, the later ones ACCUMULATE into it inside their own kernel epilogue
+    (`accumulate` of unet_conv3x3 / unet_maxpool2_bwd) and return no gradient (5 sweeps).  The order is the
+    autograd engine's (deterministic for a fixed graph); writers on different HIP streams are chained by
+    events, and the producer's backward waits for the last one."""
+
+    __slots__ = ("buf", "event")
+
+    def __init__(self):
+        self.buf = None
+        self.event = None
+
+    def begin(self, dev):
+        """-> True when the caller must accumulate into ``self.buf`` (someone wrote it already)."""
+        if self.buf is None:
+            return False
+        cur = torch.cuda.current_stream(dev)
+        if self.event is not None:
+            cur.wait_event(self.event)
+        self.buf.record_stream(cur)
+        return True
+
+    def done(self, buf, dev):
+        self.buf = buf
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+
+    def collect(self, grad, dev):
+        """Called by the producer's backward with the gradient autograd delivered."""
+        if self.buf is not None:
+            if grad.data_ptr() != self.buf.data_ptr():
+                raise RuntimeError("GradSink: autograd delivered a different tensor than the shared gradient buffer")
+            cur = torch.cuda.current_stream(dev)
+            if self.event is not None:
+                cur.wait_event(self.event)
+            self.buf.record_stream(cur)
+        self.buf = None
+        self.event = None
+
+
+SHARE_SKIP_GRADS = __import__("os").environ.get("UNET_GRAD_SINK", "1") != "0"
+
+
+def share_grad(t: torch.Tensor) -> torch.Tensor:
+    """Mark an operator output whose gradient has several consumers (model code calls this on the skips)."""
+    if SHARE_SKIP_GRADS and t.grad_fn is not None and hasattr(t.grad_fn, "out_sink"):
+        sink = GradSink()
+        t.grad_fn.out_sink = sink
+        t._unet_sink = sink
+    return t
+
+
 # ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
 class ConvBnRelu(torch.autograd.Function):
     """relu(batch_norm(conv3x3(cat([x0, x1])))) -- one third of DoubleConv
@@ -283,6 +341,8 @@ class ConvBnRelu(torch.autograd.Function):
                 "unet_bn_relu_apply")
         ctx.save_for_backward(x0, x1, y, weight, gamma, coef)
         ctx.geom = (oy, ox, training)
+        ctx.sink0 = getattr(x0, "_unet_sink", None)     # x0 is a skip with a shared gradient buffer
+        ctx.out_sink = None                              # set by share_grad() when THIS output is a skip
         return a
 
     @staticmethod
@@ -297,6 +357,8 @@ class ConvBnRelu(torch.autograd.Function):
         co, ci = weight.shape[0], weight.shape[1]
         ctot = c0 + (0 if x1 is None else x1.shape[1])
         lib, st, dev = L.lib(), _stream(), x0.device
+        if ctx.out_sink is not None:
+            ctx.out_sink.collect(da, dev)
         da = _as_nhwc(da, dtype)
         pixels = n * h * w
         dy = _nhwc_empty(n, co, h, w, dtype, dev)
@@ -333,13 +395,19 @@ class ConvBnRelu(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wp = packed(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
-            dx0 = _nhwc_empty(n, c0, h, w, dtype, dev)
+            sink = ctx.sink0
+            fan_in = sink is not None and sink.begin(dev)
+            dx0 = sink.buf if fan_in else _nhwc_empty(n, c0, h, w, dtype, dev)
             if x1 is not None:
                 dx1 = _nhwc_empty(*x1.shape, dtype, dev)
             dsrc = _views([(dy, 0, 0), None])
             ddst = _views([(dx0, 0, 0), None if x1 is None else (dx1, oy, ox)])
-            L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 0, L.K_CONV_DGRAD, st),
-                    "unet_conv3x3(dgrad)")
+            L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 1 if fan_in else 0,
+                                     L.K_CONV_DGRAD, st), "unet_conv3x3(dgrad)")
+            if sink is not None:
+                sink.done(dx0, dev)
+                if fan_in:
+                    dx0 = None              # already inside the buffer the first consumer returned
         if wgrad_done is not None:
             torch.cuda.current_stream(dev).wait_event(wgrad_done)
         return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None
@@ -358,6 +426,7 @@ class MaxPool2(torch.autograd.Function):
         y = _nhwc_empty(n, c, h // 2, w // 2, x.dtype, x.device)
         L.check(L.lib().unet_maxpool2_fwd(_DT[x.dtype], _ptr(x), n, h, w, c, _ptr(y), _stream()), "unet_maxpool2_fwd")
         ctx.save_for_backward(x)
+        ctx.sink = getattr(x, "_unet_sink", None)
         return y
 
     @staticmethod
@@ -365,9 +434,15 @@ class MaxPool2(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         n, c, h, w = x.shape
         dy = _as_nhwc(dy, x.dtype)
-        dx = _nhwc_empty(n, c, h, w, x.dtype, x.device)
-        L.check(L.lib().unet_maxpool2_bwd(_DT[x.dtype], _ptr(x), _ptr(dy), n, h, w, c, _ptr(dx), _stream()),
-                "unet_maxpool2_bwd")
+        sink = ctx.sink
+        fan_in = sink is not None and sink.begin(x.device)
+        dx = sink.buf if fan_in else _nhwc_empty(n, c, h, w, x.dtype, x.device)
+        L.check(L.lib().unet_maxpool2_bwd(_DT[x.dtype], _ptr(x), _ptr(dy), n, h, w, c, _ptr(dx), 1 if fan_in else 0,
+                                          _stream()), "unet_maxpool2_bwd")
+        if sink is not None:
+            sink.done(dx, x.device)
+            if fan_in:
+                return None
         return dx
 
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--op", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--ab", default="", help="comma list of values of --abvar to A/B interleaved in one process")
     ap.add_argument("--abvar", default="UNET_CONV_IMPL")
+    ap.add_argument("--acc", type=int, default=0, help="accumulate bit mask of the conv dgrad (dst += result)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -50,7 +51,7 @@ def main():
                                                    V([(y, 0, 0), None]), co, 0, 0, st), "fwd")
         elif a.op == "dgrad":
             run = lambda: L.check(lib.unet_conv3x3(ops._DT[dt], n, h, w, V([(gy, 0, 0), None]), p(wpd), ci,
-                                                   V([(dx, 0, 0), None]), ci, 0, 1, st), "dgrad")
+                                                   V([(dx, 0, 0), None]), ci, a.acc, 1, st), "dgrad")
         else:
             run = lambda: L.check(lib.unet_conv3x3_wgrad(ops._DT[dt], n, h, w, V([(x, 0, 0), None]), p(gy), co, p(dw),
                                                          ci, p(ws), need, st), "wgrad")
