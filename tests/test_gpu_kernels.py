@@ -70,7 +70,10 @@ def p(t):
 
 # ------------------------------------------------------------------ conv3x3 forward / dgrad / wgrad
 CONV_CASES = [  # n, cin, cout, h, w
-    (2, 64, 64, 16, 16), (1, 64, 128, 9, 21), (2, 128, 64, 8, 16), (1, 256, 128, 5, 3), (1, 64, 64, 40, 33)]
+    (2, 64, 64, 16, 16), (1, 64, 128, 9, 21), (2, 128, 64, 8, 16), (1, 256, 128, 5, 3), (1, 64, 64, 40, 33),
+    # 16-aligned frames with >= 128 input channels: the persistent LDS-DMA kernels (128- and 64-channel blocks,
+    # several work items per block, dgrad with 128 / 256 rows)
+    (2, 128, 128, 16, 32), (1, 256, 64, 32, 16), (3, 128, 64, 48, 32), (1, 512, 256, 16, 16)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -141,12 +144,13 @@ def test_conv3x3_image_layer_padded_channels(hip, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-def test_conv3x3_concat_and_centre_pad_views(hip, dtype):
+@pytest.mark.parametrize("geom", [(1, 64, 64, 64, 17, 19, 16, 16), (2, 64, 64, 64, 32, 16, 16, 16),
+                                  (1, 128, 128, 128, 16, 32, 16, 32)], ids=str)
+def test_conv3x3_concat_and_centre_pad_views(hip, dtype, geom):
     """cat([x2, pad(x1)]) (model.py:57-65) expressed as two source views, and the matching
-    two-destination data gradient."""
+    two-destination data gradient (odd frame: register-staged kernels; 16-aligned frames: LDS-DMA kernels)."""
     L, ops = hip
-    n, c0, c1, co, h, w = 1, 64, 64, 64, 17, 19
-    h1, w1 = 16, 16
+    n, c0, c1, co, h, w, h1, w1 = geom
     oy, ox = (h - h1) // 2, (w - w1) // 2
     x2, x1 = rnd("vx2", (n, c0, h, w)), rnd("vx1", (n, c1, h1, w1))
     wt = rnd("vw", (co, c0 + c1, 3, 3)) * 0.05

@@ -1100,6 +1100,330 @@ int32_t launch_dma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// conv3_pdma_kernel<BN>: PERSISTENT form of conv3_dma_kernel.  One 512-thread block per CU walks a list of
+// (output-channel tile, 16x16 pixel tile) work items; the DMA stream (patch of the next chunk, weight slabs two
+// taps ahead) simply continues into the next work item, so a block's un-overlapped prologue is paid once per
+// launch instead of once per tile, and the epilogue's stores drain behind the next tile's MFMAs.  That is what
+// the 128-input-channel layers (2 chunks = 18 steps per tile) needed; BN = 64 serves the Cout = 64 layers.
+// Work order: consecutive work items = consecutive pixel tiles of ONE channel tile, and XCD x owns a contiguous
+// run of them, so the blocks of an XCD stream the same weight slabs and neighbouring halos through its L2.
+template <int BN>
+struct CfgP {
+  static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
+  static constexpr int PSTR = 160, PPP = 10, RS = HW * PSTR;
+  static constexpr int A_INSTR = (HH * HW * PPP + 63) / 64;         // 51 wave-instructions of 1 KiB
+  static constexpr int A_BYTES = A_INSTR * 1024;
+  static constexpr int NDA = (A_INSTR + 7) / 8;                      // 7 per wave
+  static constexpr int W_BYTES = BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128) or 1 (BN 64) per wave
+  static constexpr int NSLOT = 3;
+  static constexpr int W_BASE = 2 * A_BYTES;
+  static constexpr int RED_BASE = W_BASE + NSLOT * W_BYTES;          // BatchNorm partials of the epilogue
+  static constexpr int RED_BYTES = 4 * 2 * BN * 4;
+  static constexpr int DUMMY = RED_BASE + RED_BYTES;
+  static constexpr int LDS = DUMMY + 1024;
+  static constexpr int CT = BN / 32;                                 // 16-channel MFMA tiles per wave (2 waves along channels)
+  static constexpr int NST = CT * 4;                                 // output stores per lane per work item
+};
+
+template <int BN>
+__device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
+  using C = CfgP<BN>;
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave & 1, wpx = wave >> 1;
+  const int l15 = lane & 15, kb = lane >> 4;
+
+  const int G = gridDim.x;                       // launch_pdma makes it a multiple of 8
+  const int tiles_img = P.tilesY * P.tilesX;
+  const int n_tiles = P.N * tiles_img;
+  const int total = n_tiles * P.nCo;
+  // XCD x (= blockIdx % 8) owns the contiguous logical range [x*G/8, (x+1)*G/8)
+  const int logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (logical >= total) return;
+
+  int aoff[C::CT][2], boff[4];
+#pragma unroll
+  for (int ct = 0; ct < C::CT; ++ct) {
+    const int row = wco * (BN / 2) + ct * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) aoff[ct][ks] = row * 128 + (((ks * 4 + kb) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) boff[pt] = (wpx * 4 + pt) * C::RS + l15 * C::PSTR + kb * 16;
+
+  // lane geometry of this wave's patch DMA pieces (constant), per-work offsets (a_g) derived from it
+  int a_code[C::NDA];                            // hy | hx << 8 | part << 16, -1 = pad piece
+#pragma unroll
+  for (int j = 0; j < C::NDA; ++j) {
+    const int q = (j * 8 + wave) * 64 + lane;
+    const int pix = q / C::PPP, part = q - pix * C::PPP;
+    const int hy = pix / C::HW, hx = pix - hy * C::HW;
+    a_code[j] = (pix < C::HH * C::HW && part < 8) ? (hy | (hx << 8) | (part << 16)) : -1;
+  }
+  unsigned w_g[C::NDW];
+#pragma unroll
+  for (int j = 0; j < C::NDW; ++j) {
+    const int q = (j * 8 + wave) * 64 + lane;
+    const int row = q >> 3, pos = q & 7;
+    w_g[j] = (unsigned)((row * P.wK) * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+  }
+
+  const int nchunks = P.Ctot / 64;
+  const unsigned w_tap_stride = (unsigned)P.Cout * P.wK * 2;
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)(9u * w_tap_stride), 0x00020000);
+  const unsigned img0 = (unsigned)P.src[0].H * P.src[0].W * P.src[0].C * 2;
+  const unsigned img1 = (unsigned)P.src[1].H * P.src[1].W * P.src[1].C * 2;
+
+  // ---- DMA-side state: the work item whose patches / weights are being fetched
+  unsigned a_g[2][C::NDA];
+  __amdgpu_buffer_rsrc_t a_rsrc[2];
+  unsigned d_wbase = 0;                          // byte offset of the work item's first weight row
+  bool d_live = true;
+  auto setup_dma = [&](int wk) {
+    const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
+    const int n = tile / tiles_img, r = tile - n * tiles_img;
+    const int ty0 = (r / P.tilesX) * C::TH, tx0 = (r % P.tilesX) * C::TW;
+    d_wbase = (unsigned)(cot * BN) * P.wK * 2;
+    a_rsrc[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[0].p + (size_t)n * img0), (short)0, (int)img0, 0x00020000);
+    a_rsrc[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[1].p ? P.src[1].p + (size_t)n * img1 : P.src[0].p),
+                                                  (short)0, P.src[1].p ? (int)img1 : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < C::NDA; ++j) {
+      const int code = a_code[j];
+      const int hy = code & 255, hx = (code >> 8) & 255, part = (code >> 16) & 255;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const DView S = P.src[k];
+        const int y = ty0 + hy - 1 - S.oy, x = tx0 + hx - 1 - S.ox;
+        a_g[k][j] = (code >= 0 && S.C > 0 && y >= 0 && y < S.H && x >= 0 && x < S.W)
+                        ? (unsigned)(((y * S.W + x) * S.C) * 2 + part * 16) : OOB;
+      }
+    }
+  };
+  // wave-instruction j of the patch of `chunk` (of the DMA-side work item) into patch buffer `buf`
+  auto dma_patch = [&](int chunk, int j, int buf, bool live) {
+    const int idx = j * 8 + wave;
+    live = live && idx < C::A_INSTR;
+    char* dst = live ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
+    const int ch = chunk * 64;
+    if (ch < P.src[0].C) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[0], (lds_void*)dst, 16, live ? a_g[0][j] : OOB,
+                                               (unsigned)ch * 2, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[1], (lds_void*)dst, 16, live ? a_g[1][j] : OOB,
+                                               (unsigned)(ch - P.src[0].C) * 2, 0, 0);
+    }
+  };
+  auto dma_w = [&](unsigned wbase, int chunk, int tap, int slot, bool live) {
+    const unsigned soff = live ? wbase + (unsigned)tap * w_tap_stride + (unsigned)chunk * 128 : 0u;
+#pragma unroll
+    for (int j = 0; j < C::NDW; ++j) {
+      char* dst = live ? smem + C::W_BASE + slot * C::W_BYTES + (j * 8 + wave) * 1024 : smem + C::DUMMY;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, live ? w_g[j] : OOB, soff, 0, 0);
+    }
+  };
+
+  f32x4 acc[C::CT][4];
+  auto compute = [&](int pbuf, int toff, int slot) {
+    const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
+    const char* pb = smem + pbuf + toff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[C::CT], fb[4];
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct) fa[ct] = *reinterpret_cast<const bf16x8*>(pa + aoff[ct][ks]);
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) fb[pt] = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64);
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[pt], acc[ct][pt], 0, 0, 0);
+    }
+  };
+
+  // prologue: patch of chunk 0 and the first two weight slabs of the first work item
+  setup_dma(logical);
+#pragma unroll
+  for (int j = 0; j < C::NDA; ++j) dma_patch(0, j, 0, true);
+  dma_w(d_wbase, 0, 0, 0, true);
+  dma_w(d_wbase, 0, 1, 1, true);
+
+  int pbuf_i = 0;                                 // patch buffer of the chunk being computed
+  bool after_epilogue = false;
+  for (int wk = logical; wk < total; wk += G) {
+    const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
+    const int n = tile / tiles_img, r = tile - n * tiles_img;
+    const int tyi = r / P.tilesX, txi = r - tyi * P.tilesX;
+    const int ty0 = tyi * C::TH, tx0 = txi * C::TW;
+    const int co0 = cot * BN;
+    const unsigned c_wbase = d_wbase;             // this work item's weights (DMA side moves on in the last chunk)
+    const bool has_next = wk + G < total;
+#pragma unroll
+    for (int a = 0; a < C::CT; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][b][q] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+      const bool last = c + 1 == nchunks;
+      if (last) {                                  // from here on the DMA stream belongs to the next work item
+        d_live = has_next;
+        if (has_next) setup_dma(wk + G);
+      }
+      const int pbuf = pbuf_i * C::A_BYTES;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // W(step) was issued two steps ago; younger: the previous step's [patch DMA] + NDW weight DMAs
+        // [+ the NST (+1) output stores of the previous work item's epilogue]
+        if (tap == 0 && c == 0 && after_epilogue) {
+          if (P.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + C::NST + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + C::NST) : "memory");
+        } else if (tap == 0 || tap == 8) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");          // previous tap 8 / 7: no patch DMA
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + 1) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tap < C::NDA) dma_patch(last ? 0 : c + 1, tap, pbuf_i ^ 1, last ? d_live : true);
+        if (tap + 2 < 9) dma_w(c_wbase, c, tap + 2, (tap + 2) % 3, true);
+        else if (!last) dma_w(c_wbase, c + 1, tap + 2 - 9, (tap + 2) % 3, true);
+        else dma_w(d_wbase, 0, tap + 2 - 9, (tap + 2) % 3, d_live);
+        compute(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
+      }
+      pbuf_i ^= 1;
+    }
+
+    // ---- epilogue: D of 16x16x32: col = lane&15 (pixel), rows (lane>>4)*4 + reg (4 consecutive channels).
+    // Buffer stores (out-of-range offset = dropped) so every lane issues exactly NST of them.
+    __amdgpu_buffer_rsrc_t drs[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const DViewW D = P.dst[q];
+      const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
+      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
+                                                 D.p ? (int)dimg : 0, 0x00020000);
+    }
+    float bs[C::CT][4], bq[C::CT][4];
+#pragma unroll
+    for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
+      const bool pix_ok = fy < P.H && fx < P.W;
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct) {
+        int co = co0 + wco * (BN / 2) + ct * 16 + kb * 4;
+        const bool second = co >= P.dst_split;                       // uniform per (wave, ct): dst_split % 64 == 0
+        const int accq = second ? (P.accumulate & 2) : (P.accumulate & 1);
+        const DViewW D = second ? P.dst[1] : P.dst[0];
+        if (second) co -= P.dst_split;
+        const int y = fy - D.oy, x = fx - D.ox;
+        const bool ok = pix_ok && y >= 0 && y < D.H && x >= 0 && x < D.W;
+        const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + co) * 2) : OOB;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
+        if (accq) {
+          const bf16x4 old = __builtin_bit_cast(bf16x4, second ? __builtin_amdgcn_raw_buffer_load_b64(drs[1], vo, 0, 0)
+                                                               : __builtin_amdgcn_raw_buffer_load_b64(drs[0], vo, 0, 0));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+        }
+        bf16x4 rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)v[j];
+        if (second) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), drs[1], vo, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), drs[0], vo, 0, 0);
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {              // statistics of the value as STORED (bf16-rounded)
+            const float qv = (float)rr[j];
+            bs[ct][j] += qv;
+            bq[ct][j] = fmaf(qv, qv, bq[ct][j]);
+          }
+        }
+      }
+    }
+    if (P.stats) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bs[ct][j] += __shfl_xor(bs[ct][j], m);
+            bq[ct][j] += __shfl_xor(bq[ct][j], m);
+          }
+      float* red = reinterpret_cast<float*>(smem + C::RED_BASE);     // [4 pixel-waves][2][BN]
+      if (l15 == 0) {
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cl = wco * (BN / 2) + ct * 16 + kb * 4 + j;
+            red[(wpx * 2 + 0) * BN + cl] = bs[ct][j];
+            red[(wpx * 2 + 1) * BN + cl] = bq[ct][j];
+          }
+      }
+      // LDS-only exchange: raw barrier (a __syncthreads() would also wait for the output stores)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int part = (n * P.tilesY + tyi) * P.tilesX + txi;
+      float tsum = 0.f;
+      unsigned so = OOB;
+      if (tid < 2 * BN) {
+        const int q = tid / BN, cl = tid - q * BN;
+#pragma unroll
+        for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * BN + cl];   // fixed order: deterministic
+        so = (unsigned)((((size_t)part * 2 + q) * P.Cout + co0 + cl) * 4);
+      }
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)P.stats, (short)0, (int)std::min<long long>((long long)n_tiles * 2 * P.Cout * 4, 0x7FFFFFFFLL), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tsum), srs, so, 0, 0);
+    }
+    after_epilogue = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy DMAs before the wave ends
+}
+
+__global__ __launch_bounds__(512, 1) void conv3_pdma128_kernel(const IgemmParams P) { conv3_pdma_body<128>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64_kernel(const IgemmParams P) { conv3_pdma_body<64>(P); }
+
+template <int BN>
+int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_parts) {
+  using C = CfgP<BN>;
+  IgemmParams P = Pin;
+  P.nCo = P.Cout / BN;
+  P.tilesX = cdiv(P.W, C::TW);
+  P.tilesY = cdiv(P.H, C::TH);
+  auto kern = BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
+  UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);
+  const long long stat_bytes = (long long)P.N * P.tilesY * P.tilesX * 2 * P.Cout * 4;
+  if (stat_bytes >= 0x7FFFFFFFLL) P.stats = nullptr;
+  const int blocks = (int)std::min<long long>(256, cdiv64(work, 8) * 8);   // one per CU, a multiple of 8 (XCDs)
+  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
+  if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;
+  ProfScope prof(kclass, flops, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
+  return unet_check_launch("conv3_pdma_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------
 // conv3_ws_kernel: weight-stationary 3x3 convolution for the wide-spatial / narrow-channel layers
 // (64 input channels: inc.*, up4.conv.3, their data gradients, the 128-row dgrad of up4.conv.0).
 // These layers are HBM-bound (AI ~ 288 FLOP/B at bf16), their whole filter bank is tiny (9*64*Cout bf16),
@@ -1728,9 +2052,10 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nu
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // deep layers (>= 4 input chunks: below that the un-overlapped prologue of the one block per CU costs more
     // than it saves): both operands by LDS-DMA, 512-thread blocks (impl "3" = the register-staged kernels)
-    const bool dma_ok = big && k4 && P.Ctot >= 256 && P.H % 16 == 0 && P.W % 16 == 0 &&
+    const bool dma_ok = k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 &&
                         !(impl_env && (impl_env[0] == '0' || impl_env[0] == '3'));
-    if (dma_ok) return launch_dma(P, kclass, s, stat_parts);
+    if (dma_ok && impl_env && impl_env[0] == '4' && big && P.Ctot >= 256) return launch_dma(P, kclass, s, stat_parts);
+    if (dma_ok) return big ? launch_pdma<128>(P, kclass, s, stat_parts) : launch_pdma<64>(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9) {
     if (!use3 || P.Ctot < 2 * CK4) {
