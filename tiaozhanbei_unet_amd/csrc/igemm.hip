@@ -1107,6 +1107,16 @@ int32_t launch_dma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_
 // the 128-input-channel layers (2 chunks = 18 steps per tile) needed; BN = 64 serves the Cout = 64 layers.
 // Work order: consecutive work items = consecutive pixel tiles of ONE channel tile, and XCD x owns a contiguous
 // run of them, so the blocks of an XCD stream the same weight slabs and neighbouring halos through its L2.
+// sum over the 16 lanes of a DPP row, result in every lane: 4 VALU adds with DPP operands (quad xor 1, quad xor 2,
+// half-row mirror, row mirror) instead of 4 ds_bpermute + 4 adds; fixed order -> deterministic
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
 template <int BN>
 struct CfgP {
   static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
@@ -1355,14 +1365,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
     if (P.stats) {
 #pragma unroll
-      for (int m = 1; m < 16; m <<= 1)
+      for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bs[ct][j] += __shfl_xor(bs[ct][j], m);
-            bq[ct][j] += __shfl_xor(bq[ct][j], m);
-          }
+        for (int j = 0; j < 4; ++j) {
+          bs[ct][j] = row16_sum(bs[ct][j]);
+          bq[ct][j] = row16_sum(bq[ct][j]);
+        }
       float* red = reinterpret_cast<float*>(smem + C::RED_BASE);     // [4 pixel-waves][2][BN]
       if (l15 == 0) {
 #pragma unroll
