@@ -1132,7 +1132,7 @@ struct CfgP {
   static constexpr int DUMMY = RED_BASE + RED_BYTES;
   static constexpr int LDS = DUMMY + 1024;
   static constexpr int CT = BN / 32;                                 // 16-channel MFMA tiles per wave (2 waves along channels)
-  static constexpr int NST = CT * 4;                                 // output stores per lane per work item
+  static constexpr int NST = CT / 2 * 4;                             // 16-byte output stores per lane per work item
 };
 
 template <int BN>
@@ -1325,40 +1325,54 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+    // v_permlane16_swap trades the (kb odd) rows of tile ct for the (kb even) rows of tile ct+1: afterwards lane kb
+    // holds 8 CONSECUTIVE channels -- tile ct + (kb & 1), channels 8*(kb >> 1) .. +7 -- and writes 16 bytes (half
+    // the store instructions, 64 contiguous bytes per pixel and tile pair).  Old values for the gradient fan-in
+    // come in with the same 16-byte loads and are un-swapped (the exchange is an involution) before the fp32 add.
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
       const bool pix_ok = fy < P.H && fx < P.W;
 #pragma unroll
-      for (int ct = 0; ct < C::CT; ++ct) {
-        int co = co0 + wco * (BN / 2) + ct * 16 + kb * 4;
-        const bool second = co >= P.dst_split;                       // uniform per (wave, ct): dst_split % 64 == 0
+      for (int cp = 0; cp < C::CT / 2; ++cp) {
+        const int cw = co0 + wco * (BN / 2) + cp * 32;               // first channel of the tile pair
+        const bool second = cw >= P.dst_split;                       // uniform per (wave, pair): dst_split % 64 == 0
         const int accq = second ? (P.accumulate & 2) : (P.accumulate & 1);
         const DViewW D = second ? P.dst[1] : P.dst[0];
-        if (second) co -= P.dst_split;
+        const int co = cw - (second ? P.dst_split : 0) + (kb & 1) * 16 + (kb >> 1) * 8;
         const int y = fy - D.oy, x = fx - D.ox;
         const bool ok = pix_ok && y >= 0 && y < D.H && x >= 0 && x < D.W;
         const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + co) * 2) : OOB;
-        float v[4];
+        float va[4], vb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
+        for (int j = 0; j < 4; ++j) { va[j] = acc[2 * cp][pt][j]; vb[j] = acc[2 * cp + 1][pt][j]; }
         if (accq) {
-          const bf16x4 old = __builtin_bit_cast(bf16x4, second ? __builtin_amdgcn_raw_buffer_load_b64(drs[1], vo, 0, 0)
-                                                               : __builtin_amdgcn_raw_buffer_load_b64(drs[0], vo, 0, 0));
+          const u32x4 o = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
+                                 : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
+          const auto o0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+          const auto o1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+          const bf16x4 oa = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
+          const bf16x4 ob = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+          for (int j = 0; j < 4; ++j) { va[j] += (float)oa[j]; vb[j] += (float)ob[j]; }
         }
-        bf16x4 rr;
+        bf16x4 ra, rb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)v[j];
-        if (second) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), drs[1], vo, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), drs[0], vo, 0, 0);
+        for (int j = 0; j < 4; ++j) { ra[j] = (bf16_t)va[j]; rb[j] = (bf16_t)vb[j]; }
+        const u32x2 ua = __builtin_bit_cast(u32x2, ra), ub = __builtin_bit_cast(u32x2, rb);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+        const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        if (second) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[1], vo, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(bits, drs[0], vo, 0, 0);
         if (ok) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {              // statistics of the value as STORED (bf16-rounded)
-            const float qv = (float)rr[j];
-            bs[ct][j] += qv;
-            bq[ct][j] = fmaf(qv, qv, bq[ct][j]);
+          for (int j = 0; j < 4; ++j) {              // statistics of the values as STORED (bf16-rounded)
+            const float qa = (float)ra[j], qb = (float)rb[j];
+            bs[2 * cp][j] += qa;
+            bq[2 * cp][j] = fmaf(qa, qa, bq[2 * cp][j]);
+            bs[2 * cp + 1][j] += qb;
+            bq[2 * cp + 1][j] = fmaf(qb, qb, bq[2 * cp + 1][j]);
           }
         }
       }
