@@ -1723,7 +1723,7 @@ struct CfgTW {
   static constexpr int LDS = NBUF * A_BYTES + 1024;
   static constexpr int PXT = TP / 32;                           // 4 MFMA pixel tiles per wave
   static constexpr int KGN = CIN / 16;
-  static constexpr int NST = 4 * PXT;                           // stores per wave per tile
+  static constexpr int NST = 2 * PXT;                           // 16-byte stores per wave per tile
 };
 
 struct ConvTParams {
@@ -1849,15 +1849,23 @@ __global__ __launch_bounds__(512, 1) void convt_ws_kernel(const ConvTParams P) {
       const int n = (int)(px / HW), rem = (int)(px - (long long)n * HW);
       const int y = rem / P.W, x = rem - y * P.W;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = cg * 256 + wave * 32 + 8 * g + 4 * hh;
-        const int z = r / P.Cout, co = r - z * P.Cout;
-        bf16x4 rr;
+      for (int gp = 0; gp < 2; ++gp) {
+        // v_permlane32_swap: the lower half-wave gives its g-odd run for the upper one's g-even run; each lane
+        // then owns 8 consecutive rows (16gp + 8hh ..) and writes 16 bytes
+        bf16x4 xa, xb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)(acc[pt][4 * g + j] + bias4[g][j]);
+        for (int j = 0; j < 4; ++j) {
+          xa[j] = (bf16_t)(acc[pt][8 * gp + j] + bias4[2 * gp][j]);
+          xb[j] = (bf16_t)(acc[pt][8 * gp + 4 + j] + bias4[2 * gp + 1][j]);
+        }
+        const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+        const int r = cg * 256 + wave * 32 + 16 * gp + 8 * hh;
+        const int z = r / P.Cout, co = r - z * P.Cout;
         const long long opix = ((long long)n * 2 * P.H + 2 * y + (z >> 1)) * (2 * P.W) + 2 * x + (z & 1);
         const unsigned vo = ok ? (unsigned)((opix * P.Cout + co) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), yrs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, yrs, vo, 0, 0);
       }
     }
   }
@@ -1908,7 +1916,7 @@ struct CfgTD {
   static constexpr int PW = NWAVE / RW;                         // waves along pixels (2 or 1)
   static constexpr int PXT = TP / PW / 32;                      // MFMA pixel tiles per wave (2)
   static constexpr int KGN = K / 16;
-  static constexpr int NST = 4 * PXT;
+  static constexpr int NST = 2 * PXT;
 };
 
 template <int COUT>
@@ -1995,13 +2003,16 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
       const long long px = (long long)tile * C::TP + (wp * C::PXT + pt) * 32 + l31;
       const bool ok = px < total_px;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = wr * 32 + 8 * g + 4 * hh;
-        bf16x4 rr;
+      for (int gp = 0; gp < 2; ++gp) {               // 16-byte stores (see convt_ws_kernel)
+        bf16x4 xa, xb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = (bf16_t)acc[pt][4 * g + j];
+        for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)acc[pt][8 * gp + j]; xb[j] = (bf16_t)acc[pt][8 * gp + 4 + j]; }
+        const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+        const int r = wr * 32 + 16 * gp + 8 * hh;
         const unsigned vo = ok ? (unsigned)((px * C::CIN + r) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rr), yrs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, yrs, vo, 0, 0);
       }
     }
   }
