@@ -108,6 +108,20 @@ int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_
                      const void* w_packed, int32_t c_out, const unet_view dst[2], int32_t dst_split,
                      int32_t accumulate, int32_t kclass, void* stream);
 
+/* The FIRST convolution of the network (inc.double_conv.0: nn.Conv2d(n_channels, 64, 3, padding=1), src/model.py:14
+ * reached from UNet.forward :98 / AnomalyUNet.forward :190), bf16 mode, straight from the caller's fp32 NCHW image
+ * and fp32 OIHW weight: with 9*c_in <= 32 the whole reduction is one 32-deep MFMA step, so the image is never padded
+ * to 64 channels.  y: bf16 NHWC [n][h][w][64].  partial (may be NULL: no statistics) receives *n_parts ordered
+ * BatchNorm partials [part][2][64] for unet_bn_finalize_partials (capacity: unet_conv3x3_stats_max_parts).
+ * unet_conv3x3_first_supported() tells whether a layer qualifies (c_out == 64, 9*c_in <= 32, w % 16 == 0). */
+int32_t unet_conv3x3_first_supported(int32_t c_in, int32_t c_out, int32_t h, int32_t w);
+int32_t unet_conv3x3_first_stats(int32_t n, int32_t h, int32_t w, const float* x_nchw, int32_t c_in,
+                                 const float* weight_oihw, void* y, float* partial, int32_t* n_parts, void* stream);
+/* dW[64][c_in][3][3] (fp32) = sum over pixels of dY (bf16 NHWC) x the shifted image; ordered reductions. */
+size_t unet_conv3x3_first_wgrad_workspace(int32_t n, int32_t h, int32_t w);
+int32_t unet_conv3x3_first_wgrad(int32_t n, int32_t h, int32_t w, const float* x_nchw, int32_t c_in, const void* dy,
+                                 float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The forward convolution of DoubleConv fused with the BatchNorm batch statistics (src/model.py:14-15,
  * 17-18): y = conv(concat(src)) AND per-channel partial sums (sum, sum of squares of the stored y) written
  * by the conv epilogue through wavefront reductions -- or, for kernel variants without that epilogue, by one

@@ -143,6 +143,46 @@ def test_conv3x3_image_layer_padded_channels(hip, dtype):
     check(dw, wq.grad, dtype, "image-layer wgrad", f32=5e-5, bf=5e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 12, 32), (1, 1, 16, 16), (3, 3, 33, 48), (2, 2, 5, 64)], ids=str)
+def test_conv3x3_first_layer_kernels(hip, case):
+    """unet_conv3x3_first_stats / _first_wgrad (the image layer without the 64-channel padded copy, bf16 mode)
+    against F.conv2d on the bf16-rounded operands: output, fused BatchNorm partial sums, weight gradient."""
+    L, ops = hip
+    n, ci, h, w = case
+    co, dtype = 64, torch.bfloat16
+    assert L.lib().unet_conv3x3_first_supported(ci, co, h, w) == 1
+    assert L.lib().unet_conv3x3_first_supported(4, co, h, w) == 0 and L.lib().unet_conv3x3_first_supported(ci, co, h, 24) == 0
+    x, wt, gy = rnd(f"fx{case}", (n, ci, h, w)), rnd(f"fw{case}", (co, ci, 3, 3)) * 0.3, rnd(f"fg{case}", (n, co, h, w))
+    xq, wq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True)
+    ref = F.conv2d(xq, wq, padding=1)
+    ref.backward(q(gy, dtype))
+    xd, wd = x.to(dev()).contiguous(), wt.to(dev()).contiguous()
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    cap = L.lib().unet_conv3x3_stats_max_parts(n, h, w)
+    part = torch.zeros(cap * 2 * co, device=dev())
+    nparts = C.c_int32(0)
+    L.check(L.lib().unet_conv3x3_first_stats(n, h, w, p(xd), ci, p(wd), p(y), p(part), C.byref(nparts), st()), "first fwd")
+    check(y, ref, dtype, "first-layer conv fwd")
+    assert 0 < nparts.value <= cap
+    sums = part[:nparts.value * 2 * co].view(nparts.value, 2, co).double().sum(0).cpu()
+    yf = y.float().cpu().double()
+    assert torch.allclose(sums[0], yf.sum((0, 2, 3)), rtol=1e-4, atol=1e-2), "fused sum(y)"
+    assert torch.allclose(sums[1], (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=1e-2), "fused sum(y^2)"
+    # no statistics requested (eval mode): same output
+    y2 = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    L.check(L.lib().unet_conv3x3_first_stats(n, h, w, p(xd), ci, p(wd), p(y2), None, None, st()), "first fwd eval")
+    assert torch.equal(y2, y)
+    gd = nhwc(gy, dtype)
+    dw = torch.empty(co, ci, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_first_wgrad_workspace(n, h, w)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_first_wgrad(n, h, w, p(xd), ci, p(gd), p(dw), p(ws), need, st()), "first wgrad")
+    check(dw, wq.grad, dtype, "first-layer wgrad", bf=5e-3)
+    dw2 = torch.empty_like(dw)
+    L.check(L.lib().unet_conv3x3_first_wgrad(n, h, w, p(xd), ci, p(gd), p(dw2), p(ws), need, st()), "first wgrad again")
+    assert torch.equal(dw, dw2), "ordered reductions: bitwise reproducible"
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("geom", [(1, 64, 64, 64, 17, 19, 16, 16), (2, 64, 64, 64, 32, 16, 16, 16),
                                   (1, 128, 128, 128, 16, 32, 16, 32)], ids=str)

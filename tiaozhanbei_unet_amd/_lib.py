@@ -44,6 +44,10 @@ SIGNATURES = {
     "unet_conv3x3": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, C.POINTER(View), _i, _i, _i, _p]),
     "unet_conv3x3_stats_max_parts": (_z, [_i, _i, _i]),
     "unet_conv3x3_stats": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _p, _p, _p]),
+    "unet_conv3x3_first_supported": (_i, [_i, _i, _i, _i]),
+    "unet_conv3x3_first_stats": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    "unet_conv3x3_first_wgrad_workspace": (_z, [_i, _i, _i]),
+    "unet_conv3x3_first_wgrad": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
     "unet_bn_finalize_partials": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "unet_conv3x3_wgrad_workspace": (_z, [_i, _i, _i, _i, _i]),
     "unet_conv3x3_wgrad": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _i, _p, _z, _p]),

@@ -52,10 +52,16 @@ class _HipBlock(nn.Module):
         return _DTYPES[self.precision or _default_precision]
 
 
-def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool):
+def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool, first: bool = False):
     track = training or bn.running_mean is None
-    out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                               track, bn.momentum if bn.momentum is not None else 0.1)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if first:
+        ops._require_cuda(x)
+        out = ops.FirstConvBnRelu.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        track, momentum)
+    else:
+        out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   track, momentum)
     if training and bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -108,6 +114,9 @@ class DoubleConv(_HipBlock):
         """``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
         tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly."""
         seq = self.double_conv
+        if x_up is None and ops.first_layer_ok(x, seq[0], self.compute_dtype):
+            a = _conv_bn_relu(seq[0], seq[1], x, None, self.training, first=True)      # the image layer
+            return _conv_bn_relu(seq[3], seq[4], a, None, self.training)
         x = ops.to_operator_layout(x, self.compute_dtype)
         if x_up is not None:
             x_up = ops.to_operator_layout(x_up, self.compute_dtype)

@@ -413,6 +413,87 @@ class ConvBnRelu(torch.autograd.Function):
         return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None
 
 
+class FirstConvBnRelu(torch.autograd.Function):
+    """relu(batch_norm(conv3x3(image))) for the first layer of the network (inc.double_conv.0..2,
+    /root/reference/src/model.py:14-16) in bf16 mode, straight from the caller's fp32 NCHW image: with 9*Cin <= 32
+    the reduction is one MFMA step (unet_conv3x3_first_*), no 64-channel padded copy of the image exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum):
+        _require_cuda(x, weight)
+        x = x.contiguous().float()
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        dtype = torch.bfloat16
+        lib, st, dev = L.lib(), _stream(), x.device
+        y = _nhwc_empty(n, co, h, w, dtype, dev)
+        pixels = n * h * w
+        coef = torch.empty((4, co), dtype=torch.float32, device=dev)
+        wq = weight.detach().contiguous()
+        if training:
+            cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+            part = _workspace(cap * 2 * co * 4, dev)
+            nparts = C.c_int32(0)
+            L.check(lib.unet_conv3x3_first_stats(n, h, w, _ptr(x), ci, _ptr(wq), _ptr(y), _ptr(part), C.byref(nparts), st),
+                    "unet_conv3x3_first_stats")
+            L.check(lib.unet_bn_finalize_partials(_ptr(part), nparts.value, pixels, co, _ptr(gamma), _ptr(beta),
+                                                  _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
+                                                  _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
+                    "unet_bn_finalize_partials")
+        else:
+            L.check(lib.unet_conv3x3_first_stats(n, h, w, _ptr(x), ci, _ptr(wq), _ptr(y), None, None, st),
+                    "unet_conv3x3_first_stats")
+            L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                            BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
+        a = _nhwc_empty(n, co, h, w, dtype, dev)
+        L.check(lib.unet_bn_relu_apply(_DT[dtype], _ptr(y), pixels, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(a), st),
+                "unet_bn_relu_apply")
+        ctx.save_for_backward(x, y, weight, gamma, coef)
+        ctx.training = training
+        ctx.out_sink = None
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, y, weight, gamma, coef = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("backward through BatchNorm in eval mode is not on the hot path (unsupported)")
+        dtype = torch.bfloat16
+        dt = _DT[dtype]
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        lib, st, dev = L.lib(), _stream(), x.device
+        if ctx.out_sink is not None:
+            ctx.out_sink.collect(da, dev)
+        da = _as_nhwc(da, dtype)
+        pixels = n * h * w
+        dy = _nhwc_empty(n, co, h, w, dtype, dev)
+        dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
+        ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
+        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
+                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
+                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            need = lib.unet_conv3x3_first_wgrad_workspace(n, h, w)
+            ws2 = _workspace(need, dev)
+            L.check(lib.unet_conv3x3_first_wgrad(n, h, w, _ptr(x), ci, _ptr(dy), _ptr(dw), _ptr(ws2), ws2.numel(), st),
+                    "unet_conv3x3_first_wgrad")
+        return None, dw, dgb[0], dgb[1], None, None, None, None
+
+
+FIRST_LAYER_KERNELS = __import__("os").environ.get("UNET_FIRST_LAYER", "1") != "0"
+
+
+def first_layer_ok(x: torch.Tensor, conv, dtype) -> bool:
+    """The image layer qualifies for the one-MFMA-step kernels: bf16 mode, a plain fp32 NCHW image that needs no
+    gradient, <= 3 channels into 64, width a multiple of 16."""
+    return (FIRST_LAYER_KERNELS and dtype == torch.bfloat16 and x.dim() == 4 and x.dtype == torch.float32
+            and not x.requires_grad and x.shape[1] == conv.in_channels
+            and bool(L.lib().unet_conv3x3_first_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3])))
+
+
 # ----------------------------------------------------------------------------- max pool
 class MaxPool2(torch.autograd.Function):
     """nn.MaxPool2d(2) (/root/reference/src/model.py:32)."""

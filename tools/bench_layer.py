@@ -17,7 +17,7 @@ from tiaozhanbei_unet_amd import _lib as L, ops  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kind", choices=["conv", "convt"])
+    ap.add_argument("kind", choices=["conv", "convt", "first"])
     ap.add_argument("n", type=int); ap.add_argument("cin", type=int); ap.add_argument("cout", type=int)
     ap.add_argument("h", type=int); ap.add_argument("w", type=int)
     ap.add_argument("--iters", type=int, default=20)
@@ -34,7 +34,23 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     x = torch.randn(n, ci, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
-    if a.kind == "conv":
+    if a.kind == "first":
+        xf = torch.randn(n, ci, h, w, device=dev)
+        wt = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+        gy = torch.randn(n, co, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+        y = ops._nhwc_empty(n, co, h, w, dt, dev)
+        dw = torch.empty_like(wt)
+        cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+        part = torch.empty(cap * 2 * co, device=dev)
+        nparts = C.c_int32(0)
+        need = lib.unet_conv3x3_first_wgrad_workspace(n, h, w)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        flops = 2.0 * n * h * w * co * ci * 9
+        if a.op == "fwd":
+            run = lambda: L.check(lib.unet_conv3x3_first_stats(n, h, w, p(xf), ci, p(wt), p(y), p(part), C.byref(nparts), st), "first fwd")
+        else:
+            run = lambda: L.check(lib.unet_conv3x3_first_wgrad(n, h, w, p(xf), ci, p(gy), p(dw), p(ws), need, st), "first wgrad")
+    elif a.kind == "conv":
         wt = torch.randn(co, ci, 3, 3, device=dev) * 0.05
         gy = torch.randn(n, co, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         y = ops._nhwc_empty(n, co, h, w, dt, dev)
@@ -91,7 +107,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / a.iters)
-    if a.ab:
+    if a.ab and a.kind != "first":
         outs = {}
         for v in variants:
             os.environ[a.abvar] = v
