@@ -12,6 +12,19 @@ namespace {
 
 constexpr int MAXCO = 8;
 
+// (image, pixel-in-image) of a flat pixel index: a 64-bit division costs more than the pixel's arithmetic, so the
+// common case (fewer than 2^31 pixels) divides in 32 bits
+__device__ __forceinline__ void split_pixel(long long p, long long hw, long long& n, long long& q) {
+  if (p < (1LL << 31) && hw < (1LL << 31)) {
+    const unsigned nn = (unsigned)p / (unsigned)hw;
+    n = nn;
+    q = (unsigned)p - nn * (unsigned)hw;
+  } else {
+    n = p / hw;
+    q = p - n * hw;
+  }
+}
+
 template <typename T, int TPP, int CO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long long pixels, long long hw,
                                                        int Cin, const float* __restrict__ w,
@@ -58,7 +71,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
         for (int co = 0; co < CO; ++co) if (co == g) r = acc[co];
         r += b[g];
         if (sigm) r = 1.f / (1.f + expf(-r));
-        const long long n = p[u] / hw, q = p[u] - n * hw;
+        long long n, q;
+        split_pixel(p[u], hw, n, q);
         out[(n * CO + g) * hw + q] = r;
       }
     }
@@ -101,7 +115,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
       for (int co = 0; co < CO; ++co) dl[u][co] = 0.f;
       if (p[u] < pixels) {
         Vec<T>::load(x + p[u] * Cin + g * PIECE, v[u]);
-        const long long n = p[u] / hw, q = p[u] - n * hw;
+        long long n, q;
+        split_pixel(p[u], hw, n, q);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
           float d = dout[(n * CO + co) * hw + q];

@@ -837,274 +837,21 @@ int32_t launch3(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_par
 }
 
 // ------------------------------------------------------------------------------------------------------
-// conv3_dma_kernel: the deep-layer 3x3 convolution with BOTH operands staged by LDS-DMA (bf16, Cout % 128 == 0).
-// One 512-thread block per CU owns 16x16 output pixels x 128 output channels (wave tile 64 co x 64 px on
-// v_mfma_f32_16x16x32_bf16).  Compared with conv3m16_kernel (two 256-thread blocks per CU, each staging its own
-// weight slab through registers + ds_write_b128) the weight slab of a tap is fetched ONCE per CU and written to
-// LDS by the DMA engine: half the L2 traffic per MFMA and no ds_write_b128 (79 B/clk) competing with the
-// fragment reads for the LDS array, which is what held the old kernel at 46 % MFMA busy.
+// conv3_pdma_kernel<BN>: the 3x3 convolution (forward and data gradient) of every 16-aligned bf16 layer with at least
+// 128 input channels, BOTH operands staged by LDS-DMA, persistent blocks.
+//   One 512-thread block per CU owns 16x16 output pixels x BN (128 or 64) output channels at a time (8 waves x
+//   (BN/2 co x 64 px) on v_mfma_f32_16x16x32_bf16).  Compared with conv3m16_kernel (two 256-thread blocks per CU,
+//   each staging its own weight slab through registers + ds_write_b128) the weight slab of a tap is fetched ONCE per
+//   CU and written to LDS by the DMA engine: half the L2 traffic per MFMA and no ds_write_b128 (79 B/clk) competing
+//   with the fragment reads for the LDS array, which is what held the old kernel at 46 % MFMA busy.
 //   LDS: two halo'd 18x18 pixel patches of one 64-channel chunk (rows padded to 160 B: conflict-free 16x16x32
-//   fragments) + a 3-slot ring of 128 x 64 weight slabs (unpadded 128-B rows, 16-B pieces XOR-swizzled by
+//   fragments) + a 3-slot ring of BN x 64 weight slabs (unpadded 128-B rows, 16-B pieces XOR-swizzled by
 //   (row>>1)&7 through the DMA's per-lane SOURCE address).  Weight slabs are issued two taps ahead, the next
 //   chunk's patch is issued one DMA per wave per tap during the current chunk; every wait is a counted vmcnt.
-struct CfgD {
-  static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
-  static constexpr int PSTR = 160, PPP = 10, RS = HW * PSTR;
-  static constexpr int A_INSTR = (HH * HW * PPP + 63) / 64;         // 51 wave-instructions of 1 KiB
-  static constexpr int A_BYTES = A_INSTR * 1024;
-  static constexpr int NDA = (A_INSTR + 7) / 8;                      // 7 per wave
-  static constexpr int BN = 128;
-  static constexpr int W_BYTES = BN * 128, NDW = W_BYTES / 1024 / 8; // 2 per wave
-  static constexpr int NSLOT = 3;
-  static constexpr int W_BASE = 2 * A_BYTES;
-  static constexpr int DUMMY = W_BASE + NSLOT * W_BYTES;
-  static constexpr int LDS = DUMMY + 1024;
-};
-
-__global__ __launch_bounds__(512, 1) void conv3_dma_kernel(const IgemmParams P) {
-  using C = CfgD;
-  using T = bf16_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) void lds_void;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave & 1, wpx = wave >> 1;
-  const int l15 = lane & 15, kb = lane >> 4;
-
-  int logical;
-  {
-    const int total = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
-  const int cot = logical % P.nCo;
-  int t = logical / P.nCo;
-  const int txi = t % P.tilesX;  t /= P.tilesX;
-  const int tyi = t % P.tilesY;
-  const int n = t / P.tilesY;
-  const int ty0 = tyi * C::TH, tx0 = txi * C::TW;
-  const int co0 = cot * C::BN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
-
-  int aoff[4][2], boff[4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    const int row = wco * 64 + ct * 16 + l15;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) aoff[ct][ks] = row * 128 + (((ks * 4 + kb) ^ ((row >> 1) & 7)) << 4);
-  }
-#pragma unroll
-  for (int pt = 0; pt < 4; ++pt) boff[pt] = (wpx * 4 + pt) * C::RS + l15 * C::PSTR + kb * 16;
-
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  unsigned a_g[2][C::NDA];
-#pragma unroll
-  for (int j = 0; j < C::NDA; ++j) {
-    const int q = (j * 8 + wave) * 64 + lane;
-    const int pix = q / C::PPP, part = q - pix * C::PPP;
-    const int hy = pix / C::HW, hx = pix - hy * C::HW;
-    const bool valid = pix < C::HH * C::HW && part < 8;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const DView S = P.src[k];
-      const int y = ty0 + hy - 1 - S.oy, x = tx0 + hx - 1 - S.ox;
-      a_g[k][j] = (valid && S.C > 0 && y >= 0 && y < S.H && x >= 0 && x < S.W)
-                      ? (unsigned)(((y * S.W + x) * S.C) * 2 + part * 16) : OOB;
-    }
-  }
-  unsigned w_g[C::NDW];
-#pragma unroll
-  for (int j = 0; j < C::NDW; ++j) {
-    const int q = (j * 8 + wave) * 64 + lane;
-    const int row = q >> 3, pos = q & 7;
-    w_g[j] = (unsigned)(((co0 + row) * P.wK) * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
-  }
-
-  const int nchunks = P.Ctot / 64;
-  const unsigned w_tap_stride = (unsigned)P.Cout * P.wK * 2;
-  const __amdgpu_buffer_rsrc_t w_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)(9u * w_tap_stride), 0x00020000);
-  __amdgpu_buffer_rsrc_t a_rsrc[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const DView S = P.src[k];
-    const unsigned img = (unsigned)S.H * S.W * S.C * 2;
-    a_rsrc[k] = __builtin_amdgcn_make_buffer_rsrc((void*)(S.p + (size_t)n * img), (short)0, (int)img, 0x00020000);
-  }
-
-  // one patch DMA (wave-instruction j of this wave) of `chunk` into patch buffer chunk&1; past the last
-  // chunk (or past the 51 instructions) it becomes an out-of-range load into the dummy KiB: the vmcnt
-  // bookkeeping below stays static
-  auto dma_patch = [&](int chunk, int j) {
-    const int idx = j * 8 + wave;
-    const bool live = chunk < nchunks && idx < C::A_INSTR;
-    char* dst = live ? smem + (chunk & 1) * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
-    const int ch = chunk * 64;
-    if (ch < P.src[0].C) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[0], (lds_void*)dst, 16, live ? a_g[0][j] : OOB,
-                                               (unsigned)ch * 2, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[1], (lds_void*)dst, 16, live ? a_g[1][j] : OOB,
-                                               (unsigned)(ch - P.src[0].C) * 2, 0, 0);
-    }
-  };
-  auto dma_w = [&](int chunk, int tap, int slot) {
-    if (tap >= 9) { tap -= 9; chunk += 1; }
-    const bool live = chunk < nchunks;
-    const unsigned soff = (unsigned)tap * w_tap_stride + (unsigned)chunk * 128;
-#pragma unroll
-    for (int j = 0; j < C::NDW; ++j) {
-      char* dst = live ? smem + C::W_BASE + slot * C::W_BYTES + (j * 8 + wave) * 1024 : smem + C::DUMMY;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, live ? w_g[j] : OOB, live ? soff : 0u, 0, 0);
-    }
-  };
-
-  auto compute = [&](int pbuf, int toff, int slot) {
-    const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
-    const char* pb = smem + pbuf + toff;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) fa[ct] = *reinterpret_cast<const bf16x8*>(pa + aoff[ct][ks]);
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) fb[pt] = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64);
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[pt], acc[ct][pt], 0, 0, 0);
-    }
-  };
-
-  // prologue: patch(0), W(0,0), W(0,1)
-#pragma unroll
-  for (int j = 0; j < C::NDA; ++j) dma_patch(0, j);
-  dma_w(0, 0, 0);
-  dma_w(0, 1, 1);
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int pbuf = (c & 1) * C::A_BYTES;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // W(step) was issued two steps ago; younger: the previous step's [patch DMA] + 2 weight DMAs
-      if (tap == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // previous tap 8 / 7: no patch DMA
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tap < C::NDA) dma_patch(c + 1, tap);
-      dma_w(c, tap + 2, (tap + 2) % 3);
-      compute(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy DMAs before LDS is reused / the wave ends
-
-  // ---- epilogue: D of 16x16x32: col = lane&15 (pixel), rows (lane>>4)*4 + reg (4 consecutive channels)
-  float bs[4][4], bq[4][4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
-#pragma unroll
-  for (int pt = 0; pt < 4; ++pt) {
-    const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
-    if (fy >= P.H || fx >= P.W) continue;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      int co = co0 + wco * 64 + ct * 16 + kb * 4;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
-      const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
-        const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
-      if (co >= P.dst_split) co -= P.dst_split;
-      const int y = fy - D.oy, x = fx - D.ox;
-      if (y < 0 || y >= D.H || x < 0 || x >= D.W) continue;
-      T* o = reinterpret_cast<T*>(D.p) + ((size_t)(n * D.H + y) * D.W + x) * D.C + co;
-      if (accq) {
-        bf16x4 old = *reinterpret_cast<const bf16x4*>(o);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
-      }
-      bf16x4 r;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = (bf16_t)v[j];
-      *reinterpret_cast<bf16x4*>(o) = r;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {              // statistics of the value as STORED (bf16-rounded)
-        const float q = (float)r[j];
-        bs[ct][j] += q;
-        bq[ct][j] = fmaf(q, q, bq[ct][j]);
-      }
-    }
-  }
-  if (P.stats) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bs[ct][j] += __shfl_xor(bs[ct][j], m);
-          bq[ct][j] += __shfl_xor(bq[ct][j], m);
-        }
-    __syncthreads();                               // all MFMA operand reads of the tile are done: reuse LDS
-    float* red = reinterpret_cast<float*>(smem);   // [4 pixel-waves][2][BN]
-    if (l15 == 0) {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cl = wco * 64 + ct * 16 + kb * 4 + j;
-          red[(wpx * 2 + 0) * C::BN + cl] = bs[ct][j];
-          red[(wpx * 2 + 1) * C::BN + cl] = bq[ct][j];
-        }
-    }
-    __syncthreads();
-    const int part = (n * P.tilesY + tyi) * P.tilesX + txi;
-    if (tid < 2 * C::BN) {
-      const int q = tid / C::BN, cl = tid - q * C::BN;
-      float tsum = 0.f;
-#pragma unroll
-      for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * C::BN + cl];   // fixed order: deterministic
-      P.stats[((size_t)part * 2 + q) * P.Cout + co0 + cl] = tsum;
-    }
-  }
-}
-
-int32_t launch_dma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_parts) {
-  using C = CfgD;
-  IgemmParams P = Pin;
-  P.nCo = P.Cout / C::BN;
-  P.tilesX = cdiv(P.W, C::TW);
-  P.tilesY = cdiv(P.H, C::TH);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_dma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
-  const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
-  UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "conv3_dma: grid of %lld blocks", blocks);
-  const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
-  if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;
-  ProfScope prof(kclass, flops, s);
-  hipLaunchKernelGGL(conv3_dma_kernel, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
-  return unet_check_launch("conv3_dma_kernel");
-}
-
-// ------------------------------------------------------------------------------------------------------
-// conv3_pdma_kernel<BN>: PERSISTENT form of conv3_dma_kernel.  One 512-thread block per CU walks a list of
-// (output-channel tile, 16x16 pixel tile) work items; the DMA stream (patch of the next chunk, weight slabs two
-// taps ahead) simply continues into the next work item, so a block's un-overlapped prologue is paid once per
-// launch instead of once per tile, and the epilogue's stores drain behind the next tile's MFMAs.  That is what
-// the 128-input-channel layers (2 chunks = 18 steps per tile) needed; BN = 64 serves the Cout = 64 layers.
+//   PERSISTENT: a block walks a list of (output-channel tile, pixel tile) work items; the DMA stream (patch of the
+//   next chunk, weight slabs two taps ahead) simply continues into the next work item, so a block's un-overlapped
+//   prologue is paid once per launch instead of once per tile, and the epilogue's stores drain behind the next
+//   tile's MFMAs.  That is what the 128-input-channel layers (2 chunks = 18 steps per tile) needed.
 // Work order: consecutive work items = consecutive pixel tiles of ONE channel tile, and XCD x owns a contiguous
 // run of them, so the blocks of an XCD stream the same weight slabs and neighbouring halos through its L2.
 // sum over the 16 lanes of a DPP row, result in every lane: 4 VALU adds with DPP operands (quad xor 1, quad xor 2,
@@ -1266,6 +1013,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
   bool after_epilogue = false;
+  float stat_tot = 0.f;                           // block-mode BatchNorm partial of this thread's (statistic, channel)
   for (int wk = logical; wk < total; wk += G) {
     const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
     const int n = tile / tiles_img, r = tile - n * tiles_img;
@@ -1399,14 +1147,24 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       // LDS-only exchange: raw barrier (a __syncthreads() would also wait for the output stores)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int part = (n * P.tilesY + tyi) * P.tilesX + txi;
+      // P.zdiv != 0 (block mode, every block visits every channel tile): a thread keeps the running total of ITS
+      // (statistic, channel) over the block's work items of this channel tile and writes ONE partial per block --
+      // a layer of thousands of tiles then has 256 partials to finalise instead of thousands.  Otherwise one
+      // partial per tile.  Either way exactly one (possibly dropped) store per work item: static vmcnt counts.
+      const bool flush = !P.zdiv || !has_next || (wk + G) / n_tiles != cot;
+      const int part = P.zdiv ? logical : (n * P.tilesY + tyi) * P.tilesX + txi;
       float tsum = 0.f;
       unsigned so = OOB;
       if (tid < 2 * BN) {
         const int q = tid / BN, cl = tid - q * BN;
 #pragma unroll
         for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * BN + cl];   // fixed order: deterministic
-        so = (unsigned)((((size_t)part * 2 + q) * P.Cout + co0 + cl) * 4);
+        if (P.zdiv) {
+          stat_tot += tsum;
+          tsum = stat_tot;
+          if (flush) stat_tot = 0.f;
+        }
+        if (flush) so = (unsigned)((((size_t)part * 2 + q) * P.Cout + co0 + cl) * 4);
       }
       const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)P.stats, (short)0, (int)std::min<long long>((long long)n_tiles * 2 * P.Cout * 4, 0x7FFFFFFFLL), 0x00020000);
@@ -1439,7 +1197,9 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   if (stat_bytes >= 0x7FFFFFFFLL) P.stats = nullptr;
   const int blocks = (int)std::min<long long>(256, cdiv64(work, 8) * 8);   // one per CU, a multiple of 8 (XCDs)
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
-  if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;
+  const long long n_tiles = (long long)P.N * P.tilesY * P.tilesX;
+  P.zdiv = (P.stats && n_tiles % blocks == 0) ? 1 : 0;       // block-mode statistics: every block visits every channel tile
+  if (P.stats && stat_parts) *stat_parts = P.zdiv ? blocks : (int)n_tiles;
   ProfScope prof(kclass, flops, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("conv3_pdma_kernel");
@@ -2087,7 +1847,6 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nu
     // than it saves): both operands by LDS-DMA, 512-thread blocks (impl "3" = the register-staged kernels)
     const bool dma_ok = k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 &&
                         !(impl_env && (impl_env[0] == '0' || impl_env[0] == '3'));
-    if (dma_ok && impl_env && impl_env[0] == '4' && big && P.Ctot >= 256) return launch_dma(P, kclass, s, stat_parts);
     if (dma_ok) return big ? launch_pdma<128>(P, kclass, s, stat_parts) : launch_pdma<64>(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9) {
