@@ -25,55 +25,72 @@ __device__ __forceinline__ void split_pixel(long long p, long long hw, long long
   }
 }
 
+// A wave works on 64 CONSECUTIVE pixels per iteration.  Phase 1: TPP lanes cooperate on a pixel (16 B of channels
+// each, a pixel's NHWC row is one contiguous read / write), S = TPP sub-steps cover the 64 pixels and their loads
+// are all in flight together.  Phase 2: lane = pixel, so the NCHW fp32 planes (out, dout) are read and written as
+// 256 contiguous bytes per wave -- lanes trade values between the two layouts with wave shuffles.
 template <typename T, int TPP, int CO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long long pixels, long long hw,
                                                        int Cin, const float* __restrict__ w,
                                                        const float* __restrict__ b, int sigm,
                                                        float* __restrict__ out) {
   constexpr int PIECE = ET<T>::PIECE;
-  constexpr int U = 4;                  // pixels in flight per thread (memory-level parallelism)
-  const int g = threadIdx.x % TPP;
+  constexpr int PPW = 64 / TPP, S = TPP;
+  constexpr int SB = S < 8 ? S : 8;              // sub-steps whose loads are in flight together (register budget)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane % TPP, sub = lane / TPP;
   float wr[CO][PIECE];                  // this lane's slice of the CO filters, in registers
 #pragma unroll
   for (int co = 0; co < CO; ++co)
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) wr[co][j] = w[co * Cin + g * PIECE + j];
-  const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
-  const long long nslots = (long long)gridDim.x * 256 / TPP;
-  // every lane of a wave runs the same number of iterations (shuffles need all lanes)
-  const long long iters = cdiv64(pixels, nslots * U);
-  for (long long it = 0; it < iters; ++it) {
-    float v[U][PIECE];
-    long long p[U];
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long c = blockIdx.x * 4LL + wave; c * 64 < pixels; c += nw) {
+    const long long base = c * 64;
+    float res[CO];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      p[u] = slot + (it * U + u) * nslots;
+    for (int co = 0; co < CO; ++co) res[co] = 0.f;
+#pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += SB) {
+      float v[SB][PIECE];
 #pragma unroll
-      for (int j = 0; j < PIECE; ++j) v[u][j] = 0.f;
-      if (p[u] < pixels) Vec<T>::load(x + p[u] * Cin + g * PIECE, v[u]);
-    }
+      for (int i = 0; i < SB; ++i) {
+        const long long p = base + (s0 + i) * PPW + sub;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float acc[CO];
-#pragma unroll
-      for (int co = 0; co < CO; ++co) {
-        acc[co] = 0.f;
-#pragma unroll
-        for (int j = 0; j < PIECE; ++j) acc[co] = fmaf(v[u][j], wr[co][j], acc[co]);
+        for (int j = 0; j < PIECE; ++j) v[i][j] = 0.f;
+        if (p < pixels) Vec<T>::load(x + p * Cin + g * PIECE, v[i]);
       }
 #pragma unroll
-      for (int m = 1; m < TPP; m <<= 1)
+      for (int i = 0; i < SB; ++i) {
+        const int s = s0 + i;
+        float acc[CO];
 #pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co] += __shfl_xor(acc[co], m);
-      if (p[u] < pixels && g < CO) {
-        float r = 0.f;
+        for (int co = 0; co < CO; ++co) {
+          acc[co] = 0.f;
 #pragma unroll
-        for (int co = 0; co < CO; ++co) if (co == g) r = acc[co];
-        r += b[g];
+          for (int j = 0; j < PIECE; ++j) acc[co] = fmaf(v[i][j], wr[co][j], acc[co]);
+        }
+#pragma unroll
+        for (int m = 1; m < TPP; m <<= 1)
+#pragma unroll
+          for (int co = 0; co < CO; ++co) acc[co] += __shfl_xor(acc[co], m);
+        // pixel (s, sub') of the chunk is lane s*PPW + sub' of phase 2: fetch it from lane group sub'
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const float t = __shfl(acc[co], (lane % PPW) * TPP);
+          if (lane / PPW == s) res[co] = t;
+        }
+      }
+    }
+    const long long p = base + lane;
+    if (p < pixels) {
+      long long n, q;
+      split_pixel(p, hw, n, q);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        float r = res[co] + b[co];
         if (sigm) r = 1.f / (1.f + expf(-r));
-        long long n, q;
-        split_pixel(p[u], hw, n, q);
-        out[(n * CO + g) * hw + q] = r;
+        out[(n * CO + co) * hw + q] = r;
       }
     }
   }
@@ -85,17 +102,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                                                        long long hw, int Cin, const float* __restrict__ w,
                                                        int sigm, T* __restrict__ dx, float* __restrict__ part) {
   constexpr int PIECE = ET<T>::PIECE;
-  constexpr int U = 4;
+  constexpr int PPW = 64 / TPP, S = TPP;
   __shared__ float red[4][MAXCO * 129];
-  const int g = threadIdx.x % TPP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane % TPP, sub = lane / TPP;
   float wr[CO][PIECE];
 #pragma unroll
   for (int co = 0; co < CO; ++co)
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) wr[co][j] = w[co * Cin + g * PIECE + j];
-  const long long slot = (blockIdx.x * 256LL + threadIdx.x) / TPP;
-  const long long nslots = (long long)gridDim.x * 256 / TPP;
-  const long long iters = cdiv64(pixels, nslots * U);
   float dwacc[CO][PIECE], dbacc[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
@@ -103,57 +118,69 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) dwacc[co][j] = 0.f;
   }
-  for (long long it = 0; it < iters; ++it) {
-    float v[U][PIECE], dl[U][CO];
-    long long p[U];
+  constexpr int SB = S < 8 ? S : 8;              // sub-steps whose loads are in flight together (register budget)
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long c = blockIdx.x * 4LL + wave; c * 64 < pixels; c += nw) {
+    const long long base = c * 64;
+    // phase 2 layout first: lane = pixel reads the NCHW planes coalesced
+    float dl[CO];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      p[u] = slot + (it * U + u) * nslots;
-#pragma unroll
-      for (int j = 0; j < PIECE; ++j) v[u][j] = 0.f;
-#pragma unroll
-      for (int co = 0; co < CO; ++co) dl[u][co] = 0.f;
-      if (p[u] < pixels) {
-        Vec<T>::load(x + p[u] * Cin + g * PIECE, v[u]);
+    for (int co = 0; co < CO; ++co) dl[co] = 0.f;
+    {
+      const long long p = base + lane;
+      if (p < pixels) {
         long long n, q;
-        split_pixel(p[u], hw, n, q);
+        split_pixel(p, hw, n, q);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
           float d = dout[(n * CO + co) * hw + q];
           if (sigm) { const float o = out[(n * CO + co) * hw + q]; d *= o * (1.f - o); }
-          dl[u][co] = d;
+          dl[co] = d;
+          dbacc[co] += d;
         }
       }
     }
+#pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += SB) {
+      float v[SB][PIECE];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (p[u] >= pixels) continue;
-      float d[PIECE];
+      for (int i = 0; i < SB; ++i) {
+        const long long p = base + (s0 + i) * PPW + sub;
 #pragma unroll
-      for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
-#pragma unroll
-      for (int co = 0; co < CO; ++co) {
-        if (g == 0) dbacc[co] += dl[u][co];
-#pragma unroll
-        for (int j = 0; j < PIECE; ++j) {
-          d[j] = fmaf(dl[u][co], wr[co][j], d[j]);
-          dwacc[co][j] = fmaf(dl[u][co], v[u][j], dwacc[co][j]);
-        }
+        for (int j = 0; j < PIECE; ++j) v[i][j] = 0.f;
+        if (p < pixels) Vec<T>::load(x + p * Cin + g * PIECE, v[i]);
       }
-      Vec<T>::store(dx + p[u] * Cin + g * PIECE, d);
+#pragma unroll
+      for (int i = 0; i < SB; ++i) {
+        const int s = s0 + i;
+        const long long p = base + s * PPW + sub;
+        float ds[CO], d[PIECE];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) ds[co] = __shfl(dl[co], s * PPW + sub);
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+#pragma unroll
+          for (int j = 0; j < PIECE; ++j) {
+            d[j] = fmaf(ds[co], wr[co][j], d[j]);
+            dwacc[co][j] = fmaf(ds[co], v[i][j], dwacc[co][j]);      // v is 0 and ds is 0 past the end
+          }
+        if (p < pixels) Vec<T>::store(dx + p * Cin + g * PIECE, d);
+      }
     }
   }
-  // lanes with equal g (stride TPP) hold partials of the same channels: combine across the wave
+  // dW: lanes with equal g (stride TPP) hold partials of the same channels; db: every lane holds distinct pixels
 #pragma unroll
-  for (int m = TPP; m < 64; m <<= 1) {
+  for (int m = TPP; m < 64; m <<= 1)
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-      dbacc[co] += __shfl_xor(dbacc[co], m);
+    for (int co = 0; co < CO; ++co)
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) dwacc[co][j] += __shfl_xor(dwacc[co][j], m);
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+    for (int co = 0; co < CO; ++co) dbacc[co] += __shfl_xor(dbacc[co], m);
   const int stride = Cin + 1;
   if (lane < TPP) {
 #pragma unroll
@@ -188,9 +215,9 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
 }
 
 inline int head_blocks(long long pixels, int tpp) {
-  const long long per_block = 256 / tpp;
-  long long b = cdiv64(pixels, per_block * 8);   // ~8 pixels per slot
-  if (b > 1024) b = 1024;
+  (void)tpp;
+  long long b = cdiv64(pixels, 256 * 4);         // a wave takes 64 pixels per iteration, ~4 iterations per wave
+  if (b > 2048) b = 2048;
   if (b < 1) b = 1;
   return (int)b;
 }
