@@ -14,6 +14,8 @@
 // a fixed order by reduce_kernel -> bitwise reproducible gradients.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -552,8 +554,255 @@ extern "C" int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32
   return UNET_ERR_BAD_ARG;
 }
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// convt_wgrad_ws_kernel<CIN>: weight (and bias) gradient of the wide transposed convolutions (up3: 256->128 @64x64,
+// up4: 128->64 @128x128), streaming.  dW[ci][z][co] = sum_p X[p][ci] * dYg[p][z*Cout + co], dYg[p] = the four
+// 2x2 sub-positions of dY gathered into one 4*Cout row (the gather is the DMA's per-lane source address), so the
+// whole output is a [Cin] x [4*Cout] matrix that a block keeps in REGISTERS (4 waves x (64 x 128) fp32) while
+// 32-pixel tiles of X and dYg stream through LDS by LDS-DMA (double buffered).  K = pixels is the slow NHWC axis:
+// both operands are read with ds_read_b64_tr_b16; rows are 256 / 512 B, 16-byte pieces XOR-swizzled by (row & 3) << 2
+// (on the DMA source address and on the reads) so the four pixel rows of a transposed read sit in four different
+// 64-byte bank quarters.  The bias gradient (column sums of dYg) rides along as VALU adds on the B fragments.
+// HBM-bound: every byte of X and dY is read once (twice for Cin = 256, where the output is split 2 x 2 over blocks).
+// Split-K partial slabs [split][Cin + 1][4*Cout] are summed in a fixed order -> bitwise reproducible.
+struct CtwParams {
+  const char* x; const char* dy; float* part;
+  int N, H, W, tiles, tiles_per_split;
+};
+template <int CIN>
+struct CfgCTW {
+  static constexpr int COUT = CIN / 2, NC = 2 * CIN;
+  static constexpr int TP = 32;
+  static constexpr int X_BYTES = TP * 256, D_BYTES = TP * 512, BUF = X_BYTES + D_BYTES;   // 8 + 16 KiB
+  static constexpr int NDMA = BUF / 1024 / 4;                                              // 6 per wave
+  static constexpr int RB = CIN / 128, CB = NC / 256;
+  static constexpr int LDS = 2 * BUF;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void convt_wgrad_ws_kernel(const CtwParams P) {
+  using C = CfgCTW<CIN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int rb = blockIdx.y / C::CB, cb = blockIdx.y % C::CB;
+  const int sp = blockIdx.x;
+  const int t_begin = sp * P.tiles_per_split, t_end = min(t_begin + P.tiles_per_split, P.tiles);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};            // column sums (bias gradient), wr == 0 waves only
+
+  // transposed-read lane geometry (as in wgrad_dma_kernel)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int kq = 8 * (g >> 1) + (i16 >> 2);
+  const int chb = (16 * (g & 1) + 4 * (i16 & 3)) * 2;
+  const int swz = (kq & 3) << 2;                 // rows kq, kq+4, kq+16, kq+20: same (row & 3)
+  int aoff[2], boff[4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int c = (wr * 64 + mt * 32) * 2 + chb;
+    aoff[mt] = kq * 256 + (((c >> 4) ^ swz) << 4) + (c & 15);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int c = (wc * 128 + nt * 32) * 2 + chb;
+    boff[nt] = C::X_BYTES + kq * 512 + (((c >> 4) ^ swz) << 4) + (c & 15);
+  }
+
+  // DMA geometry: instruction ii = j*4 + wave; ii < 8: X (4 pixel rows of 256 B), else dYg (2 pixel rows of 512 B)
+  int d_row[C::NDMA];
+  unsigned d_off[C::NDMA];                       // byte offset inside the pixel's source row (X) / code (dYg)
+#pragma unroll
+  for (int j = 0; j < C::NDMA; ++j) {
+    const int ii = j * 4 + wave;
+    if (ii < 8) {
+      const int row = ii * 4 + (lane >> 4), piece = lane & 15;
+      d_row[j] = row;
+      d_off[j] = (unsigned)(rb * 256 + ((piece ^ ((row & 3) << 2)) << 4));
+    } else {
+      const int row = (ii - 8) * 2 + (lane >> 5), piece = lane & 31;
+      const int n0 = cb * 256 + ((piece ^ ((row & 3) << 2)) << 3);       // first of this piece's 8 columns
+      const int z = n0 / C::COUT, co = n0 - z * C::COUT;
+      d_row[j] = row;
+      d_off[j] = (unsigned)(z | (co << 8));
+    }
+  }
+  const long long x_total = (long long)P.N * P.H * P.W * CIN * 2;
+  const long long dy_total = 2 * x_total;        // 4*H*W*COUT*2 bytes per image = 2 * H*W*CIN*2
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.x, (short)0, (int)std::min<long long>(x_total, 0x7FFFFFFFLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.dy, (short)0, (int)std::min<long long>(dy_total, 0x7FFFFFFFLL), 0x00020000);
+  const int tiles_row = P.W / C::TP;             // W % 32 == 0: a tile lies inside one image row
+
+  auto dma = [&](int tile, int buf) {
+    const int ry = tile / tiles_row, x0 = (tile - ry * tiles_row) * C::TP;   // ry = n*H + y (wave-uniform)
+    const int n = ry / P.H, y = ry - n * P.H;
+    const long long xpix0 = (long long)ry * P.W + x0;
+    const long long dpix0 = ((long long)n * 2 * P.H + 2 * y) * (2 * P.W) + 2 * x0;
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+      const int ii = j * 4 + wave;
+      char* dst = smem + buf * C::BUF + ii * 1024;
+      if (ii < 8) {
+        const unsigned vo = (unsigned)((xpix0 + d_row[j]) * (CIN * 2)) + d_off[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)dst, 16, vo, 0, 0, 0);
+      } else {
+        const int z = d_off[j] & 255, co = d_off[j] >> 8;
+        const long long dp = dpix0 + (long long)(z >> 1) * (2 * P.W) + 2 * d_row[j] + (z & 1);
+        const unsigned vo = (unsigned)(dp * (C::COUT * 2) + co * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)dst, 16, vo, 0, 0, 0);
+      }
+    }
+  };
+
+  if (t_begin < t_end) dma(t_begin, 0);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int buf = (tile - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the tile has landed
+    __builtin_amdgcn_s_barrier();                               // ... everyone's has; the other buffer is free
+    if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
+    const char* sb = smem + buf * C::BUF;
+#pragma unroll
+    for (int ks = 0; ks < C::TP / 16; ++ks) {
+      bf16x8 fa[2], fb[4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = tr_frag2(sb, aoff[mt] + ks * 16 * 256, aoff[mt] + ks * 16 * 256 + 4 * 256);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fb[nt] = tr_frag2(sb, boff[nt] + ks * 16 * 512, boff[nt] + ks * 16 * 512 + 4 * 512);
+      if (wr == 0 && rb == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[nt] += (float)fb[nt][e];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  float* slab = P.part + (size_t)sp * (CIN + 1) * C::NC;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = cb * 256 + wc * 128 + nt * 32 + l31;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 128 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[(size_t)row * C::NC + col] = acc[mt][nt][r];
+      }
+    if (wr == 0 && rb == 0) {
+      const float t = cs[nt] + __shfl_xor(cs[nt], 32);          // the two pixel halves of the fragment
+      if (hh == 0) slab[(size_t)CIN * C::NC + col] = t;
+    }
+  }
+}
+
+// dw[ci][co][z] = sum_s part[s][ci][z*Cout + co], fixed order.  grid (Cin, NC / 64), 256 threads = 64 columns x 4
+// split lanes.  Row Cin of the slabs holds the column sums of dYg: grid row Cin folds its four z into db[co].
+__global__ __launch_bounds__(256) void convt_wgrad_ws_reduce_kernel(const float* __restrict__ part, int nsplit, int CIN,
+                                                                    float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int NC = 2 * CIN, COUT = CIN / 2;
+  const int row = blockIdx.x, c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t stride = (size_t)(CIN + 1) * NC;
+  float s0 = 0.f, s1 = 0.f;
+  if (row < CIN) {
+    const int col = blockIdx.y * 64 + c;
+    const float* p = part + (size_t)row * NC + col;
+    int s = sl;
+    for (; s + 4 < nsplit; s += 8) { s0 += p[(size_t)s * stride]; s1 += p[(size_t)(s + 4) * stride]; }
+    if (s < nsplit) s0 += p[(size_t)s * stride];
+  } else {
+    // bias: blocks y < Cout / 64 only; co = y*64 + c, the four z columns are summed per split in z order
+    const int co = blockIdx.y * 64 + c;
+    if (co < COUT) {
+      const float* p = part + (size_t)CIN * NC + co;
+      for (int s = sl; s < nsplit; s += 4) {
+        const float* q = p + (size_t)s * stride;
+        s0 += ((q[0] + q[COUT]) + q[2 * COUT]) + q[3 * COUT];
+      }
+    }
+  }
+  red[sl][c] = s0 + s1;
+  __syncthreads();
+  if (sl == 0) {
+    const float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    if (row < CIN) {
+      const int col = blockIdx.y * 64 + c;
+      const int z = col / COUT, co = col - z * COUT;
+      dw[((size_t)row * COUT + co) * 4 + z] = t;
+    } else if (blockIdx.y * 64 + c < COUT) {
+      db[blockIdx.y * 64 + c] = t;
+    }
+  }
+}
+
+template <int CIN>
+int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w, float* dw, float* db, void* workspace,
+                              size_t workspace_bytes, hipStream_t s) {
+  using C = CfgCTW<CIN>;
+  const long long px = (long long)n * h * w;
+  CtwParams P{(const char*)x, (const char*)dy, (float*)workspace, n, h, w, (int)(px / C::TP), 0};
+  const int yb = C::RB * C::CB;
+  int nsplit = 512 / yb;
+  if (nsplit > P.tiles) nsplit = P.tiles;
+  P.tiles_per_split = (P.tiles + nsplit - 1) / nsplit;
+  nsplit = (P.tiles + P.tiles_per_split - 1) / P.tiles_per_split;
+  const size_t need = (size_t)nsplit * (CIN + 1) * C::NC * sizeof(float);
+  UNET_REQUIRE(workspace_bytes >= need, UNET_ERR_WORKSPACE, "unet_convt2x2_wgrad: workspace %zu < %zu", workspace_bytes, need);
+  auto kern = convt_wgrad_ws_kernel<CIN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  {
+    ProfScope prof(UNET_K_CONVT_WGRAD, 2.0 * px * 4.0 * C::COUT * CIN, s);
+    hipLaunchKernelGGL(kern, dim3(nsplit, yb), dim3(256), C::LDS, s, P);
+    int32_t rc = unet_check_launch("convt_wgrad_ws_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(convt_wgrad_ws_reduce_kernel, dim3(CIN + 1, C::NC / 64), dim3(256), 0, s, (const float*)workspace,
+                       nsplit, CIN, dw, db);
+  }
+  return unet_check_launch("convt_wgrad_ws_reduce_kernel");
+}
+
+inline bool convt_wgrad_ws_ok(int dtype, int n, int h, int w, int c_in, int c_out) {
+  const char* e = getenv("UNET_CONVT_IMPL");                // tuning hook: "0" = generic kernels
+  const long long xb = (long long)n * h * w * c_in * 2;
+  return dtype == UNET_BF16 && (c_in == 128 || c_in == 256) && c_out * 2 == c_in && w % 32 == 0 &&
+         2 * xb < 0x7FFFFFFFLL && !(e && e[0] == '0');
+}
+inline size_t convt_wgrad_ws_bytes(int n, int h, int w, int c_in) {
+  const long long tiles = (long long)n * h * w / 32;
+  const int yb = (c_in / 128) * (c_in / 128);
+  long long nsplit = 512 / yb;
+  if (nsplit > tiles) nsplit = tiles;
+  return (size_t)nsplit * (c_in + 1) * (2 * c_in) * sizeof(float);
+}
+
+}  // namespace
+
 extern "C" size_t unet_convt2x2_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
-  return make_plan<4>(n, h, w, pad64(c_in), pad64(c_out)).bytes;
+  size_t bytes = make_plan<4>(n, h, w, pad64(c_in), pad64(c_out)).bytes;
+  if (convt_wgrad_ws_ok(UNET_BF16, n, h, w, c_in, c_out)) bytes = std::max(bytes, convt_wgrad_ws_bytes(n, h, w, c_in));
+  return bytes;
 }
 
 extern "C" int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x,
@@ -563,6 +812,10 @@ extern "C" int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int3
   UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_wgrad: bad dims");
   UNET_REQUIRE(c_in % 64 == 0 && c_out % 64 == 0, UNET_ERR_UNSUPPORTED,
                "unet_convt2x2_wgrad: channels %d -> %d must be multiples of 64", c_in, c_out);
+  if (convt_wgrad_ws_ok(dtype, n, h, w, c_in, c_out)) {
+    return c_in == 128 ? launch_convt_wgrad_ws<128>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, (hipStream_t)stream)
+                       : launch_convt_wgrad_ws<256>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
+  }
   const Plan pl = make_plan<4>(n, h, w, c_in, c_out);
   UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_convt2x2_wgrad: workspace %zu < %zu",
                workspace_bytes, pl.bytes);
