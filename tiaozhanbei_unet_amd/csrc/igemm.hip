@@ -986,21 +986,58 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   };
 
   f32x4 acc[C::CT][4];
+  // One tap = two 32-channel half-steps (ks) of CT x 4 MFMAs.  The fragment reads are software-pipelined BY HAND and
+  // pinned with sched_barriers: left alone, hipcc funnels the weight fragments through one register quad and waits
+  // for each ds_read right before its MFMAs (eight exposed LDS latencies per tap; SQ_WAIT_ANY 44 %).  Here every
+  // fragment is requested at least four MFMAs before its first use; at most 11 fragments are live.
   auto compute = [&](int pbuf, int toff, int slot) {
     const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
     const char* pb = smem + pbuf + toff;
+    auto ra = [&](int ks, int ct) { return *reinterpret_cast<const bf16x8*>(pa + aoff[ct][ks]); };
+    auto rb = [&](int ks, int pt) { return *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64); };
+    auto mm = [&](int ct, const bf16x8& fa, const bf16x8 (&fb)[4]) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[C::CT], fb[4];
+      for (int pt = 0; pt < 4; ++pt)
+        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[pt], acc[ct][pt], 0, 0, 0);
+    };
+    bf16x8 fb0[4], fb1[4];
 #pragma unroll
-      for (int ct = 0; ct < C::CT; ++ct) fa[ct] = *reinterpret_cast<const bf16x8*>(pa + aoff[ct][ks]);
+    for (int pt = 0; pt < 4; ++pt) fb0[pt] = rb(0, pt);
+    if constexpr (C::CT == 4) {
+      bf16x8 a0 = ra(0, 0), a1 = ra(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a2 = ra(0, 2), a3 = ra(0, 3);
+      mm(0, a0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      fb1[0] = rb(1, 0); fb1[1] = rb(1, 1);
+      mm(1, a1, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      fb1[2] = rb(1, 2); fb1[3] = rb(1, 3);
+      mm(2, a2, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = ra(1, 0); a1 = ra(1, 1);
+      mm(3, a3, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      a2 = ra(1, 2);
+      mm(0, a0, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      a3 = ra(1, 3);
+      mm(1, a1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(2, a2, fb1);
+      mm(3, a3, fb1);
+    } else {
+      // 8 MFMAs per half-step cannot cover an LDS round trip: the whole second half-step is fetched behind the first
+      bf16x8 a0 = ra(0, 0), a1 = ra(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) fb[pt] = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64);
-#pragma unroll
-      for (int ct = 0; ct < C::CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
-          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[pt], acc[ct][pt], 0, 0, 0);
+      for (int pt = 0; pt < 4; ++pt) fb1[pt] = rb(1, pt);
+      const bf16x8 a2 = ra(1, 0), a3 = ra(1, 1);
+      mm(0, a0, fb0);
+      mm(1, a1, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(0, a2, fb1);
+      mm(1, a3, fb1);
     }
   };
 
@@ -1388,17 +1425,29 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
     const char* pb = smem + cur * C::A_BYTES;
+    // 36 (tap, 16-channel group) steps of PXT MFMAs; the pixel fragments of step i+2 are requested before the MFMAs
+    // of step i and pinned there (left alone, hipcc requests them one MFMA ahead: the LDS round trip showed)
+    constexpr int DEPTH = 2;
+    auto frag = [&](int i, int pt) {
+      const int tap = i >> 2, kg = i & 3;
+      return *reinterpret_cast<const bf16x8*>(pb + boff[pt] + (tap / 3) * C::RS + (tap % 3) * C::PSTR + kg * 32);
+    };
+    bf16x8 ring[DEPTH + 1][C::PXT];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = (tap / 3) * C::RS + (tap % 3) * C::PSTR;
+    for (int i = 0; i < DEPTH; ++i)
 #pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
+      for (int pt = 0; pt < C::PXT; ++pt) ring[i][pt] = frag(i, pt);
 #pragma unroll
-        for (int pt = 0; pt < C::PXT; ++pt) {
-          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + toff + kg * 32);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap * 4 + kg], fb, acc[pt], 0, 0, 0);
-        }
+    for (int i = 0; i < 36; ++i) {
+      if (i + DEPTH < 36) {
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt) ring[(i + DEPTH) % (DEPTH + 1)][pt] = frag(i + DEPTH, pt);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[i], ring[i % (DEPTH + 1)][pt], acc[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped)
@@ -1593,13 +1642,30 @@ __global__ __launch_bounds__(512, 1) void convt_ws_kernel(const ConvTParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
     const char* pb = smem + cur * C::A_BYTES + l31 * C::RSTR + hh * 16;
+    {
+      // pixel fragments requested two K-groups ahead of their MFMAs, pinned (see conv3_ws_kernel)
+      constexpr int DEPTH = 2;
+      bf16x8 ring[DEPTH + 1][C::PXT];
 #pragma unroll
-    for (int kg = 0; kg < C::KGN; ++kg)
+      for (int i = 0; i < DEPTH && i < C::KGN; ++i)
 #pragma unroll
-      for (int pt = 0; pt < C::PXT; ++pt) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + kg * 32);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], fb, acc[pt], 0, 0, 0);
+        for (int pt = 0; pt < C::PXT; ++pt)
+          ring[i][pt] = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + i * 32);
+#pragma unroll
+      for (int kg = 0; kg < C::KGN; ++kg) {
+        if (kg + DEPTH < C::KGN) {
+#pragma unroll
+          for (int pt = 0; pt < C::PXT; ++pt)
+            ring[(kg + DEPTH) % (DEPTH + 1)][pt] =
+                *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + (kg + DEPTH) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], ring[kg % (DEPTH + 1)][pt], acc[pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
 
     // ---- epilogue: scatter to (2y+zk, 2x+zl); exactly NST buffer stores per wave
 #pragma unroll
@@ -1751,13 +1817,30 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
     const char* pb = smem + cur * C::A_BYTES + (wp * C::PXT * 32 + l31) * C::RSTR + hh * 16;
+    {
+      // pixel fragments requested two K-groups ahead of their MFMAs, pinned (see conv3_ws_kernel)
+      constexpr int DEPTH = 2;
+      bf16x8 ring[DEPTH + 1][C::PXT];
 #pragma unroll
-    for (int kg = 0; kg < C::KGN; ++kg)
+      for (int i = 0; i < DEPTH && i < C::KGN; ++i)
 #pragma unroll
-      for (int pt = 0; pt < C::PXT; ++pt) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + kg * 32);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], fb, acc[pt], 0, 0, 0);
+        for (int pt = 0; pt < C::PXT; ++pt)
+          ring[i][pt] = *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + i * 32);
+#pragma unroll
+      for (int kg = 0; kg < C::KGN; ++kg) {
+        if (kg + DEPTH < C::KGN) {
+#pragma unroll
+          for (int pt = 0; pt < C::PXT; ++pt)
+            ring[(kg + DEPTH) % (DEPTH + 1)][pt] =
+                *reinterpret_cast<const bf16x8*>(pb + pt * 32 * C::RSTR + (kg + DEPTH) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kg], ring[kg % (DEPTH + 1)][pt], acc[pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
       const long long px = (long long)tile * C::TP + (wp * C::PXT + pt) * 32 + l31;
