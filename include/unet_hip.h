@@ -222,6 +222,23 @@ int32_t unet_ssim_loss(const float* img1, const float* img2, int32_t planes, int
                        size_t workspace_bytes, void* stream);
 
 /* ---- optimiser (torch.optim.Adam of get_optimizer, src/train_utils.py:266) -------------- */
+/* ---- Multi-class segmentation head of the Gear/Kolektor trainers (src/metrics.py) ------------------------ */
+/* CombinedSegmentationLoss.forward (src/metrics.py:300-335): loss = ce_weight * CE(class weights, ignore_index)
+ * + dice_weight * dice_loss(softmax(logits)) (:233-261) + focal_weight * focal_loss (:264-282), value AND gradient.
+ * logits: fp32 NCHW [n][c][hw], c <= 8; target: int64 [n][hw]; class_weights: [c] or NULL; ignore_index < 0: none.
+ * input_is_prob != 0: `logits` already holds probabilities (stand-alone dice_loss(pred, target)); Dice term only.
+ * loss[4] = {total, ce, dice, focal}; dlogits (same shape as logits) may be NULL.  Ordered reductions. */
+size_t unet_seg_loss_workspace(int32_t n, int32_t c, int64_t hw);
+int32_t unet_seg_loss(const float* logits, const int64_t* target, int32_t n, int32_t c, int64_t hw,
+                      const float* class_weights, int64_t ignore_index, int32_t input_is_prob, float ce_weight,
+                      float dice_weight, float focal_weight, float focal_alpha, float focal_gamma, float* loss,
+                      float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
+/* SegmentationMetrics.update (src/metrics.py:22-45): labels[n][hw] = argmax over classes (the FIRST maximum wins
+ * ties, as torch.argmax), confusion[t][p] += 1 over the pixels whose target is a class and not ignore_index.
+ * labels or confusion (with target) may be NULL.  Integer atomics: exact. */
+int32_t unet_seg_confusion(const float* logits, const int64_t* target, int32_t n, int32_t c, int64_t hw,
+                           int64_t ignore_index, int64_t* labels, int64_t* confusion, void* stream);
+
 /* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
  * gradient pre-scale (1/world_size under data parallelism). step is 1-based. */
 int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -71,6 +71,9 @@ SIGNATURES = {
     "unet_loss_mse_focal": (_i, [_p, _p, _l, _p, _p, _l, _f, _f, _p, _p, _p, _p, _z, _p]),
     "unet_ssim_workspace": (_z, [_i, _i, _i]),
     "unet_ssim_loss": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "unet_seg_loss_workspace": (_z, [_i, _i, _l]),
+    "unet_seg_loss": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _f, _f, _f, _f, _f, _p, _p, _p, _z, _p]),
+    "unet_seg_confusion": (_i, [_p, _p, _i, _i, _l, _l, _p, _p, _p]),
     "unet_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _i, _p]),
 }
 
