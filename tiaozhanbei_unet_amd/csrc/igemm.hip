@@ -562,8 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv3m16_kernel(const IgemmParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave % C::WCO, wpx = wave / C::WCO;
-  const int l31 = lane & 31, hh = lane >> 5;
-
+  
   int logical;
   {
     const int total = gridDim.x, b = blockIdx.x;
@@ -885,7 +884,6 @@ struct CfgP {
 template <int BN>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   using C = CfgP<BN>;
-  using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -1252,7 +1250,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
 // of tile t+1 is prefetched (buffer loads -> registers) while tile t computes and lands in the other LDS
 // buffer; one barrier per tile, no weight traffic through LDS at all, 72 MFMAs per wave between barriers.
 struct CfgWS {
-  static constexpr int WTH = 16, WTW = 16, WNPIX = WTH * WTW;   // 256-pixel tiles: halo overhead 1.27x
+  static constexpr int WTH = 16, WTW = 16;                      // 256-pixel tiles: halo overhead 1.27x
   static constexpr int HH = WTH + 2, HW = WTW + 2;
   static constexpr int PSTR = 128 + 16;
   static constexpr int RS = (HW * PSTR + 255) / 256 * 256;
@@ -1270,7 +1268,6 @@ struct CfgWS {
 template <bool ACC>
 __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, int tiles_per_block) {
   using C = CfgWS;
-  typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave & 1, wpx = wave >> 1;

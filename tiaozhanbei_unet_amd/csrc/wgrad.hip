@@ -586,7 +586,6 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_ws_kernel(const CtwParams 
   using C = CfgCTW<CIN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
-  constexpr unsigned OOB = 0xFFFFFFF0u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave & 1, wc = wave >> 1;
   const int l31 = lane & 31, hh = lane >> 5;
