@@ -108,6 +108,17 @@ int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_
                      const void* w_packed, int32_t c_out, const unet_view dst[2], int32_t dst_split,
                      int32_t accumulate, int32_t kclass, void* stream);
 
+/* Inference form of conv + BatchNorm(eval) + ReLU (src/model.py:14-19 under model.eval(), src/test.py:68): BatchNorm's
+ * running statistics are folded into the layer -- scale = gamma / sqrt(running_var + eps) into the packed weights
+ * (unet_pack_conv_weight_folded; scale / shift from unet_bn_eval_coeffs), shift = beta - running_mean * scale as the
+ * bias of the convolution's epilogue, followed by max(., 0) when relu != 0.  One kernel per layer, the activation is
+ * written once (y: dense NHWC [n][h][w][c_out] in the compute dtype). */
+int32_t unet_pack_conv_weight_folded(const float* w, const float* scale, void* out, int32_t c_out, int32_t c_in,
+                                     int32_t rows, int32_t k, int32_t dtype, void* stream);
+int32_t unet_conv3x3_bias_relu(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                               const void* w_packed, int32_t c_out, void* y, const float* bias, int32_t relu,
+                               void* stream);
+
 /* The FIRST convolution of the network (inc.double_conv.0: nn.Conv2d(n_channels, 64, 3, padding=1), src/model.py:14
  * reached from UNet.forward :98 / AnomalyUNet.forward :190), bf16 mode, straight from the caller's fp32 NCHW image
  * and fp32 OIHW weight: with 9*c_in <= 32 the whole reduction is one 32-deep MFMA step, so the image is never padded

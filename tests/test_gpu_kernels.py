@@ -143,6 +143,36 @@ def test_conv3x3_image_layer_padded_channels(hip, dtype):
     check(dw, wq.grad, dtype, "image-layer wgrad", f32=5e-5, bf=5e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 16), (1, 64, 128, 9, 21), (2, 128, 128, 16, 32), (1, 256, 64, 32, 16),
+                                  (1, 128, 64, 5, 7)], ids=str)
+def test_conv3x3_folded_batchnorm_inference(hip, dtype, case):
+    """unet_pack_conv_weight_folded + unet_conv3x3_bias_relu (inference: BatchNorm(eval) folded into the layer, shift and
+    ReLU in the conv epilogue) against relu(batch_norm_eval(conv(x))) -- every conv kernel family (weight-stationary,
+    persistent LDS-DMA with 128- and 64-channel blocks, register-staged fallback)."""
+    L, ops = hip
+    n, ci, co, h, w = case
+    x = rnd(f"bx{case}", (n, ci, h, w))
+    wt = rnd(f"bw{case}", (co, ci, 3, 3)) * (1.0 / (3 * ci ** 0.5))
+    gamma, beta = rnd(f"bg{case}", (co,)) * 0.5 + 1.0, rnd(f"bb{case}", (co,)) * 0.3
+    rm, rv = rnd(f"bm{case}", (co,)) * 0.2, rnd(f"bv{case}", (co,), kind="uniform") + 0.5
+    scale = gamma / torch.sqrt(rv + 1e-5)
+    shift = beta - rm * scale
+    ref = torch.relu(F.conv2d(q(x, dtype), q(wt * scale[:, None, None, None], dtype), padding=1) + shift[None, :, None, None])
+    dt = ops._DT[dtype]
+    ss = torch.empty(2, co, device=dev())
+    gd, bd, md, vd, wd, xd = (t.to(dev()) for t in (gamma, beta, rm, rv, wt, x))      # keep the device copies alive
+    xn = nhwc(xd, dtype)
+    L.check(L.lib().unet_bn_eval_coeffs(co, p(gd), p(bd), p(md), p(vd), C.c_float(1e-5), p(ss[0]), p(ss[1]), st()), "coeffs")
+    wq = torch.empty(9 * co * ci, dtype=dtype, device=dev())
+    L.check(L.lib().unet_pack_conv_weight_folded(p(wd), p(ss[0]), p(wq), co, ci, co, ci, dt, st()), "fold")
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    L.check(L.lib().unet_conv3x3_bias_relu(dt, n, h, w, views(L, [(xn, 0, 0), None]), p(wq), co, p(y), p(ss[1]), 1, st()),
+            "conv bias relu")
+    check(y, ref, dtype, "folded conv + BN(eval) + ReLU", f32=5e-5, bf=2e-2)
+    assert float(y.float().min()) >= 0.0
+
+
 @pytest.mark.parametrize("case", [(2, 3, 12, 32), (1, 1, 16, 16), (3, 3, 33, 48), (2, 2, 5, 64)], ids=str)
 def test_conv3x3_first_layer_kernels(hip, case):
     """unet_conv3x3_first_stats / _first_wgrad (the image layer without the 64-channel padded copy, bf16 mode)

@@ -252,6 +252,30 @@ def test_skip_gradient_fan_in_matches_autograd_sums(precision, two_streams):
     assert worst <= (1e-6 if precision == "fp32" else 2e-2), worst
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_inference_with_folded_batchnorm_matches_the_unfused_path(precision):
+    """model.eval() under no_grad runs one kernel per conv layer (BatchNorm folded into weights + epilogue bias/ReLU,
+    SURVEY 8f-4); with autograd recording (or UNET_FOLD_BN=0) the separate apply pass runs.  Same results."""
+    from tiaozhanbei_unet_amd import ops
+    model, _ = make_model(("anomaly_unet", 3, 1, False), precision)
+    model.eval()
+    x = W.make_input("fold:x", (2, 3, 48, 32)).to(DEV)
+    with torch.no_grad():
+        r1, a1 = model(x)
+    try:
+        ops.FOLD_EVAL_BN = False
+        with torch.no_grad():
+            r0, a0 = model(x)
+    finally:
+        ops.FOLD_EVAL_BN = True
+    tol = 2e-5 if precision == "fp32" else 3e-2
+    assert maxabs(r1, r0) <= tol and maxabs(a1, a0) <= tol, (maxabs(r1, r0), maxabs(a1, a0))
+    if precision == "fp32":
+        ref_r, ref_a = O.anomaly_unet_forward({k: v.cpu() for k, v in model.state_dict().items()}, x.cpu(), training=False)[:2]
+        assert maxabs(r1, ref_r) <= 1e-3 and maxabs(a1, ref_a) <= 1e-3
+        assert torch.equal(a1.cpu() > 0.5, ref_a > 0.5)
+
+
 @pytest.mark.parametrize("model", ["anomaly_unet", "unet"])
 def test_cli_train_then_test_roundtrip(tmp_path, model):
     """BASELINE configs[0]-style plumbing (2 epochs, bs=4) through the train/test CLIs on an MVTec-layout toy

@@ -42,6 +42,8 @@ SIGNATURES = {
     "unet_pack_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_pack_weights_batched": (_i, [_p, _i, _i, _p]),
     "unet_conv3x3": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, C.POINTER(View), _i, _i, _i, _p]),
+    "unet_pack_conv_weight_folded": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_bias_relu": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _p, _i, _p]),
     "unet_conv3x3_stats_max_parts": (_z, [_i, _i, _i]),
     "unet_conv3x3_stats": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _p, _p, _p]),
     "unet_conv3x3_first_supported": (_i, [_i, _i, _i, _i]),

@@ -48,7 +48,7 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 // out index -> source parameter index; zero where the padded GEMM dims exceed the parameter's.
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int rows,
-                                   int K, int mode, long long total) {
+                                   int K, int mode, long long total, const float* __restrict__ scale) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -57,7 +57,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
       long long t = i / K;
       const int co = (int)(t % rows);
       const int tap = (int)(t / rows);
-      if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
+      if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap] * (scale ? scale[co] : 1.f);   // BN fold
     } else if (mode == UNET_PACK_CONV_DGRAD) {   // out[tap'][ci][co] <- w[co][ci][8 - tap']
       const int co = (int)(i % K);
       long long t = i / K;
@@ -359,9 +359,25 @@ extern "C" int32_t unet_pack_weight(const float* w, void* out, int32_t c_out, in
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_PACK, 0.0, s);
   if (dtype == UNET_BF16)
-    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (bf16_t*)out, c_out, c_in, rows, k, mode, total);
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (bf16_t*)out, c_out, c_in, rows, k, mode, total, (const float*)nullptr);
   else
-    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (float*)out, c_out, c_in, rows, k, mode, total);
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (float*)out, c_out, c_in, rows, k, mode, total, (const float*)nullptr);
+  return unet_check_launch("pack_weight_kernel");
+}
+
+extern "C" int32_t unet_pack_conv_weight_folded(const float* w, const float* scale, void* out, int32_t c_out, int32_t c_in,
+                                                int32_t rows, int32_t k, int32_t dtype, void* stream) {
+  UNET_REQUIRE(w && scale && out, UNET_ERR_BAD_ARG, "unet_pack_conv_weight_folded: null pointer");
+  UNET_REQUIRE(c_out > 0 && c_in > 0 && rows >= c_out && k >= c_in, UNET_ERR_BAD_ARG, "unet_pack_conv_weight_folded: bad dims");
+  const long long total = 9LL * rows * k;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_PACK, 0.0, s);
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (bf16_t*)out, c_out, c_in, rows, k,
+                       (int)UNET_PACK_CONV_FWD, total, scale);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (float*)out, c_out, c_in, rows, k,
+                       (int)UNET_PACK_CONV_FWD, total, scale);
   return unet_check_launch("pack_weight_kernel");
 }
 

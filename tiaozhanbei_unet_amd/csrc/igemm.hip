@@ -40,6 +40,7 @@ struct IgemmParams {
   const float* bias;
   int dst_split;
   int accumulate;
+  int relu;         // != 0: max(., 0) after the bias (inference with BatchNorm folded into weights + bias)
   int imul, gtaps;  // input position = frame*imul + gather tap (convT dgrad: 2, 4)
   int omul, nZ;     // output position = frame*omul + z tap     (convT fwd:   2, 4)
   int zdiv;         // > 0: GEMM row = z*zdiv + co (convT fwd as one GEMM with 4*Cout rows)
@@ -245,6 +246,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams P) {
         if (P.bias) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += P.bias[co + j];
+        }
+        if (P.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
         const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
@@ -507,6 +512,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const IgemmParams P) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][4 * g + j];
+        if (P.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += P.bias[co + j];
+        }
+        if (P.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
         const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
         const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
         if (co >= P.dst_split) co -= P.dst_split;
@@ -740,6 +753,14 @@ __global__ __launch_bounds__(256, 2) void conv3m16_kernel(const IgemmParams P) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[ct][pt][j];
+      if (P.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += P.bias[co + j];
+      }
+      if (P.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
       const int accq = (co < P.dst_split) ? (P.accumulate & 1) : (P.accumulate & 2);   // per-view accumulate bit
         const DViewW D = (co < P.dst_split) ? P.dst[0] : P.dst[1];
       if (co >= P.dst_split) co -= P.dst_split;
@@ -1129,6 +1150,15 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         float va[4], vb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { va[j] = acc[2 * cp][pt][j]; vb[j] = acc[2 * cp + 1][pt][j]; }
+        if (P.bias) {                                // inference: BatchNorm shift (+ ReLU) of the folded layer
+          const float* bp = P.bias + cw + kb * 4;   // native accumulator layout: tile 2cp (+16: tile 2cp+1), rows kb*4..+3
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { va[j] += bp[j]; vb[j] += bp[16 + j]; }
+        }
+        if (P.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { va[j] = fmaxf(va[j], 0.f); vb[j] = fmaxf(vb[j], 0.f); }
+        }
         if (accq) {
           const u32x4 o = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
                                  : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
@@ -1467,8 +1497,20 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
             xb[j] = (bf16_t)(acc[pt][8 * gp + 4 + j] + (float)ob[j]);
           }
         } else {
+          float fa4[4], fb4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)acc[pt][8 * gp + j]; xb[j] = (bf16_t)acc[pt][8 * gp + 4 + j]; }
+          for (int j = 0; j < 4; ++j) { fa4[j] = acc[pt][8 * gp + j]; fb4[j] = acc[pt][8 * gp + 4 + j]; }
+          if (P.bias) {                              // inference: BatchNorm shift (+ ReLU) of the folded layer
+            const float* bp = P.bias + cg * C::ROWS + wco * 32 + 16 * gp + 4 * hh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { fa4[j] += bp[j]; fb4[j] += bp[8 + j]; }
+          }
+          if (P.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { fa4[j] = fmaxf(fa4[j], 0.f); fb4[j] = fmaxf(fb4[j], 0.f); }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)fa4[j]; xb[j] = (bf16_t)fb4[j]; }
         }
         const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
         const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
@@ -1974,6 +2016,32 @@ extern "C" int32_t unet_conv3x3(int32_t dtype, int32_t n, int32_t h, int32_t w, 
   if (dtype == UNET_BF16) return dispatch<bf16_t, 9>(P, kclass, s);
   if (dtype == UNET_F32) return dispatch<float, 9>(P, kclass, s);
   unet_set_error("unet_conv3x3: dtype %d", dtype);
+  return UNET_ERR_BAD_ARG;
+}
+
+extern "C" int32_t unet_conv3x3_bias_relu(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
+                                          const void* w_packed, int32_t c_out, void* y, const float* bias,
+                                          int32_t relu, void* stream) {
+  UNET_REQUIRE(src && w_packed && src[0].ptr && y && bias, UNET_ERR_BAD_ARG, "unet_conv3x3_bias_relu: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0 && c_out > 0, UNET_ERR_BAD_ARG, "unet_conv3x3_bias_relu: bad dims");
+  IgemmParams P{};
+  P.src[0] = in_view(src[0]);
+  P.src[1] = src[1].ptr ? in_view(src[1]) : DView{nullptr, 0, 0, 0, 0, 0};
+  P.dst[0] = DViewW{(char*)y, c_out, h, w, 0, 0};
+  P.dst[1] = DViewW{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = P.src[0].C + P.src[1].C;
+  P.Cout = c_out;
+  P.wK = P.Ctot;
+  P.w = (const char*)w_packed;
+  P.bias = bias;
+  P.relu = relu;
+  P.dst_split = c_out;
+  P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UNET_BF16) return dispatch<bf16_t, 9>(P, UNET_K_CONV_FWD, s);
+  if (dtype == UNET_F32) return dispatch<float, 9>(P, UNET_K_CONV_FWD, s);
+  unet_set_error("unet_conv3x3_bias_relu: dtype %d", dtype);
   return UNET_ERR_BAD_ARG;
 }
 

@@ -60,8 +60,10 @@ def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool, 
         out = ops.FirstConvBnRelu.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         track, momentum)
     else:
+        # inference (eval mode, no autograd recording): BatchNorm folded into the layer, one kernel
+        fold = (not track) and not torch.is_grad_enabled()
         out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   track, momentum)
+                                   track, momentum, fold)
     if training and bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)

@@ -290,6 +290,39 @@ def share_grad(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+FOLD_EVAL_BN = __import__("os").environ.get("UNET_FOLD_BN", "1") != "0"
+_folded = {}                                             # id(weight) -> (weakref to it, {(dtype, ctot): (stamp, payload)})
+_train_generation = 0                                    # bumped by every training forward (see below)
+
+
+def _folded_pack(weight, gamma, beta, running_mean, running_var, co, ctot, dtype):
+    """(packed folded weights, shift) of an eval-mode conv+BN layer.  Cached per weight Parameter; an entry is valid
+    while the autograd version counters of the five tensors AND the training generation are unchanged -- the HIP
+    kernels update running statistics (and fused optimisers update parameters) through raw pointers, which no version
+    counter sees, so any training forward in between invalidates every entry."""
+    stamp = (_train_generation, weight._version, gamma._version, beta._version, running_mean._version,
+             running_var._version, running_mean.data_ptr(), running_var.data_ptr(), weight.data_ptr())
+    import weakref
+    slot = _folded.get(id(weight))
+    if slot is None or slot[0]() is not weight:          # first use, or the id was recycled by another tensor
+        key = id(weight)
+        slot = (weakref.ref(weight, lambda _r, k=key: _folded.pop(k, None)), {})
+        _folded[key] = slot
+    per_weight = slot[1]
+    hit = per_weight.get((dtype, ctot))
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    lib, st, dev = L.lib(), _stream(), weight.device
+    ss = torch.empty((2, co), dtype=torch.float32, device=dev)
+    L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
+                                    _ptr(ss[0]), _ptr(ss[1]), st), "unet_bn_eval_coeffs")
+    wq = torch.empty(9 * co * ctot, dtype=dtype, device=dev)
+    L.check(lib.unet_pack_conv_weight_folded(_ptr(weight.detach()), _ptr(ss[0]), _ptr(wq), co, weight.shape[1], co, ctot,
+                                             _DT[dtype], st), "unet_pack_conv_weight_folded")
+    per_weight[(dtype, ctot)] = (stamp, (wq, ss[1]))
+    return wq, ss[1]
+
+
 # ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
 class ConvBnRelu(torch.autograd.Function):
     """relu(batch_norm(conv3x3(cat([x0, x1])))) -- one third of DoubleConv
@@ -297,7 +330,7 @@ class ConvBnRelu(torch.autograd.Function):
     of Up.forward, centre-padded to x0's size (src/model.py:57-65) without materialising pad or cat."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum):
+    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum, fold=False):
         _require_cuda(x0, weight)
         dtype = x0.dtype
         dt = _DT[dtype]
@@ -314,12 +347,16 @@ class ConvBnRelu(torch.autograd.Function):
         if not (ci <= ctot < ci + 64):
             raise ValueError(f"conv weight expects {ci} input channels, activations carry {ctot}")
         lib, st, dev = L.lib(), _stream(), x0.device
-        wp = packed(weight, L.PACK_CONV_FWD, co, ctot, dtype)
         y = _nhwc_empty(n, co, h, w, dtype, dev)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         pixels = n * h * w
         coef = torch.empty((4, co), dtype=torch.float32, device=dev)   # mean, istd, scale, shift
+        fold = bool(fold) and FOLD_EVAL_BN and not training
+        if not fold:
+            wp = packed(weight, L.PACK_CONV_FWD, co, ctot, dtype)
         if training:
+            global _train_generation
+            _train_generation += 1
             # conv + BatchNorm batch statistics in one call: the conv epilogue reduces sum / sum-of-squares per
             # channel with wavefront shuffles (or one extra streaming pass for kernels without that epilogue)
             cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
@@ -331,6 +368,13 @@ class ConvBnRelu(torch.autograd.Function):
                                                   _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
                                                   _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
                     "unet_bn_finalize_partials")
+        elif fold:
+            # inference: BatchNorm(eval) folded into the layer -- scale into the packed weights, shift + ReLU in the
+            # convolution's epilogue: one kernel, the activation is written once
+            wf = _folded_pack(weight, gamma, beta, running_mean, running_var, co, ctot, dtype)
+            L.check(lib.unet_conv3x3_bias_relu(dt, n, h, w, src, _ptr(wf[0]), co, _ptr(y), _ptr(wf[1]), 1, st),
+                    "unet_conv3x3_bias_relu")
+            return y
         else:
             dst = _views([(y, 0, 0), None])
             L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
@@ -410,7 +454,7 @@ class ConvBnRelu(torch.autograd.Function):
                     dx0 = None              # already inside the buffer the first consumer returned
         if wgrad_done is not None:
             torch.cuda.current_stream(dev).wait_event(wgrad_done)
-        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None
+        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None, None
 
 
 class FirstConvBnRelu(torch.autograd.Function):
