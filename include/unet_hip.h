@@ -250,6 +250,16 @@ int32_t unet_seg_loss(const float* logits, const int64_t* target, int32_t n, int
 int32_t unet_seg_confusion(const float* logits, const int64_t* target, int32_t n, int32_t c, int64_t hw,
                            int64_t ignore_index, int64_t* labels, int64_t* confusion, void* stream);
 
+/* ---- nn.Dropout2d of SegmentationUNet's bottleneck (src/model.py:129,146): y = x * scale[n][c] on dense NHWC; the
+ * caller draws scale = bernoulli(1-p)/(1-p) per (image, channel); the same call is the backward (dx = dy * scale). */
+int32_t unet_channel_scale(int32_t dtype, const void* x, const float* scale, int32_t n, int64_t hw, int32_t c, void* y,
+                           void* stream);
+/* ---- compute_anomaly_score (src/utils.py:205-215): score[n][hw] = mean_c (recon - image)^2 (l1 != 0: mean_c |.|)
+ * over fp32 NCHW planes, image_score[n] = mean over pixels (ordered partials). */
+size_t unet_anomaly_score_workspace(int32_t n, int64_t hw);
+int32_t unet_anomaly_score(const float* recon, const float* image, int32_t n, int32_t c, int64_t hw, int32_t l1,
+                           float* score, float* image_score, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
  * gradient pre-scale (1/world_size under data parallelism). step is 1-based. */
 int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -107,3 +107,54 @@ def test_unet_multiclass_training_step_with_segmentation_loss():
     m.update(out, t)
     assert int(m.confusion_matrix.sum()) == t.numel() and m.total_samples == t.numel()
     assert torch.equal(m.argmax(out), torch.argmax(out, dim=1))
+
+
+def test_segmentation_unet_is_unet_plus_bottleneck_dropout():
+    """SegmentationUNet (reference src/model.py:111-153): identical to UNet in eval mode and with dropout=0; in training
+    the bottleneck is multiplied by the [N, C, 1, 1] bernoulli(1-p)/(1-p) noise torch's Dropout2d draws."""
+    import tiaozhanbei_unet_amd as P
+    from tiaozhanbei_unet_amd import model as Mdl
+    torch.manual_seed(3)
+    seg = P.SegmentationUNet(3, 4, dropout=0.5, precision="fp32").to(DEV)
+    ref = P.UNet(3, 4, precision="fp32").to(DEV)
+    assert list(seg.state_dict().keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict(seg.state_dict())
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+    seg.eval(); ref.eval()
+    with torch.no_grad():
+        assert torch.equal(seg(x), ref(x))
+    seg.train(); ref.train()
+    torch.manual_seed(11)
+    y = seg(x)
+    torch.manual_seed(11)
+    noise = torch.empty(2, 1024, 1, 1, device=DEV).bernoulli_(0.5).div_(0.5)
+    assert 0.3 < float((noise == 0).float().mean()) < 0.7
+    ref.load_state_dict(seg.state_dict())                      # (running statistics moved in seg's forward: restore both)
+    seg2 = P.SegmentationUNet(3, 4, dropout=0.5, precision="fp32").to(DEV).train()
+    seg2.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+    # expected: the same blocks with x5 scaled by the noise in torch arithmetic
+    Mdl._pack_cache(seg2)
+    x1, x2, x3, x4, x5 = Mdl._encoder(seg2, x)
+    x5s = (x5.float() * noise).to(x5.dtype).contiguous(memory_format=torch.channels_last)
+    exp = seg2.outc(seg2.up4(seg2.up3(seg2.up2(seg2.up1(x5s, x4), x3), x2), x1))
+    # y was produced with running stats one step behind exp's model, but training-mode BN uses batch statistics: equal
+    assert float((y - exp).abs().max()) <= 1e-5 * max(1.0, float(exp.abs().max()))
+    y.square().mean().backward()
+    g = [p.grad for p in seg.parameters()]
+    assert all(t is not None and bool(torch.isfinite(t).all()) for t in g)
+    seg0 = P.SegmentationUNet(3, 4, dropout=0.0, precision="fp32").to(DEV).train()
+    assert isinstance(seg0.dropout, torch.nn.Identity)
+
+
+def test_anomaly_score_kernel_matches_the_reference_formula():
+    from tiaozhanbei_unet_amd import ops, utils
+    torch.manual_seed(5)
+    recon, img = torch.rand(3, 3, 40, 24, device=DEV), torch.rand(3, 3, 40, 24, device=DEV)
+    for l1 in (False, True):
+        score, per_image = ops.anomaly_score(recon, img, l1=l1)
+        d = recon - img
+        ref = d.abs().mean(1) if l1 else (d * d).mean(1)         # src/utils.py:205-215
+        assert float((score - ref).abs().max()) < 1e-6
+        assert float((per_image - ref.flatten(1).mean(1)).abs().max()) < 1e-6
+    assert float((utils.compute_anomaly_score(recon, img) - ((recon - img) ** 2).mean(1)).abs().max()) < 1e-6
+    assert torch.allclose(utils.compute_anomaly_score(recon.cpu(), img.cpu(), "l1"), (recon - img).abs().mean(1).cpu())

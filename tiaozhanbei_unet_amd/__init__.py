@@ -5,11 +5,11 @@ Drop-in for the hot path of ukeSJTU/tiaozhanbei-unet: ``model`` mirrors src/mode
 loss / argmax / confusion matrix).  Compute happens only in libunet_hip.so.
 """
 from . import _lib
-from .model import (AnomalyUNet, DoubleConv, Down, OutConv, UNet, Up, set_default_precision,
+from .model import (AnomalyUNet, DoubleConv, Down, OutConv, SegmentationUNet, UNet, Up, set_default_precision,
                     set_precision)
 from .train_utils import CombinedLoss, SSIMLoss, get_optimizer, get_scheduler, train_epoch, validate_epoch
 from .metrics import CombinedSegmentationLoss, SegmentationMetrics
 
-__all__ = ["AnomalyUNet", "UNet", "DoubleConv", "Down", "Up", "OutConv", "CombinedLoss", "SSIMLoss",
+__all__ = ["AnomalyUNet", "UNet", "SegmentationUNet", "DoubleConv", "Down", "Up", "OutConv", "CombinedLoss", "SSIMLoss",
            "train_epoch", "validate_epoch", "get_optimizer", "get_scheduler", "set_precision",
            "set_default_precision", "CombinedSegmentationLoss", "SegmentationMetrics"]

@@ -437,6 +437,105 @@ extern "C" int32_t unet_upsample_bilinear2x_bwd(int32_t dtype, const void* dy, i
   EW_DISPATCH("bilinear2x_bwd_kernel", bilinear2x_bwd_kernel, (long long)n * h * w * c, (const T*)dy, (T*)dx, n, h, w, c);
 }
 
+// ------------------------------------------------------------------------------- Dropout2d / anomaly score
+namespace {
+
+// y[n][p][c] = x[n][p][c] * scale[n][c]   (nn.Dropout2d on the bottleneck of SegmentationUNet, src/model.py:129,146:
+// scale = bernoulli(1-p) / (1-p) per (image, channel); the same kernel is its backward)
+template <typename T>
+__global__ void channel_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
+                                     long long hw, int C, long long total) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int G = C / PIECE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    const long long n = i / G / hw;
+    float v[PIECE];
+    Vec<T>::load(x + i * PIECE, v);
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) v[j] *= scale[n * C + g * PIECE + j];
+    Vec<T>::store(y + i * PIECE, v);
+  }
+}
+
+// score[n][p] = mean_c (recon - image)^2 (or |.|) over fp32 NCHW planes (compute_anomaly_score, src/utils.py:205-215);
+// image_score[n] = mean_p score[n][p] through ordered block partials (the image-level score of src/test.py)
+__global__ __launch_bounds__(256) void anomaly_score_kernel(const float* __restrict__ recon, const float* __restrict__ image,
+                                                           int C, long long hw, int l1, float* __restrict__ score,
+                                                           float* __restrict__ part) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  for (long long q = blockIdx.x * 256LL + threadIdx.x; q < hw; q += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = recon[((long long)n * C + c) * hw + q] - image[((long long)n * C + c) * hw + q];
+      s += l1 ? fabsf(d) : d * d;
+    }
+    s /= (float)C;
+    score[(long long)n * hw + q] = s;
+    acc += s;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void anomaly_score_finalize_kernel(const float* __restrict__ part, int N, int nb, long long hw,
+                                              float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += (double)part[(size_t)n * nb + b];
+  out[n] = (float)(s / (double)hw);
+}
+
+}  // namespace
+
+extern "C" int32_t unet_channel_scale(int32_t dtype, const void* x, const float* scale, int32_t n, int64_t hw, int32_t c,
+                                      void* y, void* stream) {
+  UNET_REQUIRE(x && scale && y, UNET_ERR_BAD_ARG, "unet_channel_scale: null pointer");
+  UNET_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_channel_scale: c=%d", c);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_POOL, 0.0, s);
+  if (dtype == UNET_BF16) {
+    const long long total = (long long)n * hw * c / 8;
+    hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)x, scale,
+                       (bf16_t*)y, (long long)hw, c, total);
+  } else {
+    const long long total = (long long)n * hw * c / 4;
+    hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)x, scale,
+                       (float*)y, (long long)hw, c, total);
+  }
+  return unet_check_launch("channel_scale_kernel");
+}
+
+extern "C" size_t unet_anomaly_score_workspace(int32_t n, int64_t hw) {
+  (void)hw;
+  return (size_t)n * 64 * sizeof(float);
+}
+
+extern "C" int32_t unet_anomaly_score(const float* recon, const float* image, int32_t n, int32_t c, int64_t hw,
+                                      int32_t l1, float* score, float* image_score, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(recon && image && score && image_score && workspace, UNET_ERR_BAD_ARG, "unet_anomaly_score: null pointer");
+  UNET_REQUIRE(n > 0 && c > 0 && hw > 0, UNET_ERR_BAD_ARG, "unet_anomaly_score: bad dims");
+  UNET_REQUIRE(workspace_bytes >= unet_anomaly_score_workspace(n, hw), UNET_ERR_WORKSPACE, "unet_anomaly_score: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  long long nb = cdiv64(hw, 256 * 4);
+  if (nb > 64) nb = 64;
+  ProfScope prof(UNET_K_LOSS, 0.0, s);
+  hipLaunchKernelGGL(anomaly_score_kernel, dim3((unsigned)nb, n), dim3(256), 0, s, recon, image, c, (long long)hw, l1, score,
+                     (float*)workspace);
+  int32_t rc = unet_check_launch("anomaly_score_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(anomaly_score_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, n, (int)nb,
+                     (long long)hw, image_score);
+  return unet_check_launch("anomaly_score_finalize_kernel");
+}
+
 extern "C" int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay,
                                   float grad_scale, int32_t step, void* stream) {

@@ -3,7 +3,7 @@
 Drop-in surface (same class names, constructor / forward signatures, attributes and
 ``state_dict`` key layout as /root/reference/src/model.py): ``DoubleConv`` (:6-23),
 ``Down`` (:26-37), ``Up`` (:40-66), ``OutConv`` (:69-75), ``UNet`` (:78-108),
-``AnomalyUNet`` (:156-210).
+``SegmentationUNet`` (:111-153), ``AnomalyUNet`` (:156-210).
 
 The stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` children are kept
 ONLY as parameter holders -- same registration order, hence the same default
@@ -246,6 +246,53 @@ class UNet(_HipBlock):
         _pack_cache(self)
         with _BatchedCounters():
             x1, x2, x3, x4, x5 = _encoder(self, x)
+            y = self.up1(x5, x4)
+            y = self.up2(y, x3)
+            y = self.up3(y, x2)
+            y = self.up4(y, x1)
+            return self.outc(y)
+
+
+class SegmentationUNet(_HipBlock):
+    """UNet for multi-class semantic segmentation (Gear / Kolektor trainers, reference src/model.py:111-153): the UNet
+    above with ``nn.Dropout2d(dropout)`` on the bottleneck x5.  Same attributes and state_dict keys as the reference."""
+
+    def __init__(self, n_channels=3, n_classes=4, bilinear=False, dropout=0.1, precision=None):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+        self.precision = precision
+        self.inc = DoubleConv(n_channels, 64, precision=precision)
+        self.down1 = Down(64, 128, precision=precision)
+        self.down2 = Down(128, 256, precision=precision)
+        self.down3 = Down(256, 512, precision=precision)
+        factor = 2 if bilinear else 1
+        self.down4 = Down(512, 1024 // factor, precision=precision)
+        self.dropout = nn.Dropout2d(dropout) if dropout > 0 else nn.Identity()      # holder of p / training flag
+        self.up1 = Up(1024, 512 // factor, bilinear, precision=precision)
+        self.up2 = Up(512, 256 // factor, bilinear, precision=precision)
+        self.up3 = Up(256, 128 // factor, bilinear, precision=precision)
+        self.up4 = Up(128, 64, bilinear, precision=precision)
+        self.outc = OutConv(64, n_classes, precision=precision)
+
+    def _bottleneck_dropout(self, x5):
+        d = self.dropout
+        if not isinstance(d, nn.Dropout2d) or not self.training or d.p == 0:
+            return x5
+        if d.p >= 1:
+            return ops.ChannelDropout.apply(x5, torch.zeros(x5.shape[0], x5.shape[1], device=x5.device))
+        # the noise tensor torch's feature dropout draws: [N, C, 1, 1] bernoulli(1-p) / (1-p) in the input's arithmetic
+        noise = torch.empty((x5.shape[0], x5.shape[1], 1, 1), dtype=torch.float32, device=x5.device)
+        noise.bernoulli_(1 - d.p).div_(1 - d.p)
+        return ops.ChannelDropout.apply(x5, noise.view(x5.shape[0], x5.shape[1]))
+
+    def forward(self, x):
+        ops._require_cuda(x)
+        _pack_cache(self)
+        with _BatchedCounters():
+            x1, x2, x3, x4, x5 = _encoder(self, x)
+            x5 = self._bottleneck_dropout(x5)
             y = self.up1(x5, x4)
             y = self.up2(y, x3)
             y = self.up3(y, x2)

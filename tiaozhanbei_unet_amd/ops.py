@@ -538,6 +538,48 @@ def first_layer_ok(x: torch.Tensor, conv, dtype) -> bool:
             and bool(L.lib().unet_conv3x3_first_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3])))
 
 
+class ChannelDropout(torch.autograd.Function):
+    """nn.Dropout2d on an NHWC activation (SegmentationUNet's bottleneck, /root/reference/src/model.py:129,146):
+    ``noise`` = bernoulli(1-p)/(1-p) per (image, channel), drawn by the caller exactly as torch's feature dropout
+    draws it; y = x * noise, dx = dy * noise (unet_channel_scale)."""
+
+    @staticmethod
+    def forward(ctx, x, noise):
+        _require_cuda(x, noise)
+        n, c, h, w = x.shape
+        y = _nhwc_empty(n, c, h, w, x.dtype, x.device)
+        L.check(L.lib().unet_channel_scale(_DT[x.dtype], _ptr(x), _ptr(noise), n, h * w, c, _ptr(y), _stream()),
+                "unet_channel_scale")
+        ctx.save_for_backward(noise)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (noise,) = ctx.saved_tensors
+        n, c, h, w = dy.shape
+        dy = _as_nhwc(dy, dy.dtype)
+        dx = _nhwc_empty(n, c, h, w, dy.dtype, dy.device)
+        L.check(L.lib().unet_channel_scale(_DT[dy.dtype], _ptr(dy), _ptr(noise), n, h * w, c, _ptr(dx), _stream()),
+                "unet_channel_scale")
+        return dx, None
+
+
+def anomaly_score(reconstruction, original, l1=False):
+    """(score map [N, H, W], image score [N]) of compute_anomaly_score (/root/reference/src/utils.py:205-215)."""
+    _require_cuda(reconstruction, original)
+    r = reconstruction.detach().contiguous().float()
+    o = original.detach().contiguous().float()
+    n, c = r.shape[0], r.shape[1]
+    hw = int(r.numel() // (n * c))
+    score = torch.empty((n,) + tuple(r.shape[2:]), dtype=torch.float32, device=r.device)
+    img = torch.empty(n, dtype=torch.float32, device=r.device)
+    lib = L.lib()
+    ws = _workspace(lib.unet_anomaly_score_workspace(n, hw), r.device)
+    L.check(lib.unet_anomaly_score(_ptr(r), _ptr(o), n, c, hw, 1 if l1 else 0, _ptr(score), _ptr(img), _ptr(ws), ws.numel(),
+                                   _stream()), "unet_anomaly_score")
+    return score, img
+
+
 # ----------------------------------------------------------------------------- max pool
 class MaxPool2(torch.autograd.Function):
     """nn.MaxPool2d(2) (/root/reference/src/model.py:32)."""

@@ -55,13 +55,15 @@ def load_checkpoint(model, optimizer, filepath, device):
 
 
 def compute_anomaly_score(reconstruction, original, method="mse"):
-    """Per-pixel channel-mean error map (host-side evaluation helper, not on the training path)."""
+    """Per-pixel channel-mean error map (reference src/utils.py:205-215; 'ssim' is the reference's MSE placeholder).
+    GPU tensors run in libunet_hip.so (unet_anomaly_score); host tensors (plots, reports) stay host arithmetic."""
+    if method not in ("mse", "ssim", "l1"):
+        raise ValueError(f"Unknown method: {method}")
+    if reconstruction.is_cuda and original.is_cuda and reconstruction.dim() == 4:
+        from . import ops
+        return ops.anomaly_score(reconstruction, original, l1=(method == "l1"))[0]
     diff = reconstruction - original
-    if method in ("mse", "ssim"):
-        return (diff * diff).mean(dim=1)
-    if method == "l1":
-        return diff.abs().mean(dim=1)
-    raise ValueError(f"Unknown method: {method}")
+    return diff.abs().mean(dim=1) if method == "l1" else (diff * diff).mean(dim=1)
 
 
 def calculate_metrics(y_true, y_pred, y_scores=None):
