@@ -111,7 +111,35 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const unet_pa
       tile[i] = (a < As && bb < Bs) ? w[((size_t)a * Bs + b0) * taps + r] : 0.f;
     }
     __syncthreads();
-    // TA*TB*taps outputs; innermost = the 64-wide contiguous axis
+    // TA*TB*taps outputs; innermost = the 64-wide contiguous axis.  Eight consecutive outputs per thread -> one
+    // 16-byte store (bf16) when the contiguous extent is a multiple of 8 (it is: GEMM dims are padded to 64)
+    if ((((along_b ? Bp : Ap) & 7) == 0) && ((d.k & 7) == 0)) {
+      for (int gi = threadIdx.x; gi < TA * TB * taps / 8; gi += 256) {
+        const int inner0 = (gi & 7) * 8, rest = gi >> 3;
+        const int tap = rest % taps, outer = rest / taps;
+        const int al0 = along_b ? outer : inner0, bl0 = along_b ? inner0 : outer;
+        const int a = a0 + al0, bb = b0 + bl0;
+        if (a >= Ap || bb >= Bp) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[(al0 + (along_b ? 0 : e)) * run + (bl0 + (along_b ? e : 0)) * taps + tap];
+        size_t o;
+        if (mode == UNET_PACK_CONV_FWD) o = ((size_t)tap * d.rows + a) * d.k + bb;
+        else if (mode == UNET_PACK_CONV_DGRAD) o = ((size_t)(8 - tap) * d.rows + bb) * d.k + a;
+        else if (mode == UNET_PACK_CONVT_FWD) o = ((size_t)tap * d.rows + bb) * d.k + a;
+        else o = ((size_t)a * 4 + tap) * d.k + bb;
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 r;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(out + o) = r;
+        } else {
+          *reinterpret_cast<f32x4*>(out + o) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      }
+      continue;
+    }
     for (int i = threadIdx.x; i < TA * TB * taps; i += 256) {
       const int inner = i & 63, rest = i >> 6;
       const int tap = rest % taps, outer = rest / taps;          // outer: the 8-wide axis
