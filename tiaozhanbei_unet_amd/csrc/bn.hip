@@ -135,16 +135,17 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
 }
 
 // dgamma, dbeta and the three per-channel coefficients of  dy = A*dz + B*y + K
+template <int TL, int TC>
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C,
                                                               float inv_count, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ istd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coefs) {
-  __shared__ double red[2][FL][FC];
-  const int c = blockIdx.x * FC + (threadIdx.x % FC), rl = threadIdx.x / FC;
+  __shared__ double red[2][TL][TC];
+  const int c = blockIdx.x * TC + (threadIdx.x % TC), rl = threadIdx.x / TC;
   double s, ss;
-  sum_parts(part, nparts, C, c, rl, red, s, ss);
+  sum_parts_t<TL, TC>(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
   const float db = (float)s, dg = (float)ss;
   dbeta[c] = db;
@@ -351,7 +352,7 @@ extern "C" int32_t unet_bn_finalize_partials(const float* partial, int32_t n_par
                "unet_bn_finalize_partials: running_mean/var must both be given or both NULL");
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s);
-  if (n_parts >= 1024)
+  if (n_parts >= 128)      // 64 partial-lanes per channel: fewer dependent loads per thread on this latency-bound kernel
     hipLaunchKernelGGL((bn_finalize_train_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, partial, n_parts, c,
                        (double)pixels, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_istd,
                        scale, shift);
@@ -445,8 +446,12 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
                    : launch_reduce<float, 1>(y, da, pixels, c, scale, shift, save_mean, save_istd, part, pl, s);
   if (rc) return rc;
   const float inv = (float)(1.0 / (double)pixels);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
-                     save_mean, save_istd, dgamma, dbeta, coefs);
+  if (pl.nparts >= 128)      // latency-bound: 64 partial-lanes per channel
+    hipLaunchKernelGGL((bn_finalize_bwd_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
+                       save_mean, save_istd, dgamma, dbeta, coefs);
+  else
+    hipLaunchKernelGGL((bn_finalize_bwd_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
+                       save_mean, save_istd, dgamma, dbeta, coefs);
   rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
   if (dtype == UNET_BF16) {
