@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
 inline int head_blocks(long long pixels, int tpp) {
   (void)tpp;
   long long b = cdiv64(pixels, 256 * 4);         // a wave takes 64 pixels per iteration, ~4 iterations per wave
-  if (b > 2048) b = 2048;
+  if (b > 1024) b = 1024;                        // (every block leaves a partial for the weight-gradient finalize)
   if (b < 1) b = 1;
   return (int)b;
 }
