@@ -160,58 +160,49 @@ class SegmentationMetrics:
                 "unet_seg_confusion")
         return out
 
-    # ---- ratios of the matrix: host arithmetic, as in the reference (metrics.py:47-140)
+    # ---- ratios of the C x C matrix (host arithmetic; reference metrics.py:47-140 computes the same quantities)
+    def _ratios(self):
+        """Every per-class ratio from one pass over the matrix: rows = ground truth, columns = prediction."""
+        cm = self.confusion_matrix.astype(np.float64)
+        hit = np.diagonal(cm)
+        truth_total, pred_total = cm.sum(axis=1), cm.sum(axis=0)
+        floor = 1e-8                                   # the reference's guard against empty classes
+
+        def ratio(num, den):
+            return num / np.maximum(den, floor)
+
+        precision, recall = ratio(hit, pred_total), ratio(hit, truth_total)
+        return {"iou": ratio(hit, truth_total + pred_total - hit), "dice": ratio(2 * hit, truth_total + pred_total),
+                "precision": precision, "recall": recall, "f1": ratio(2 * precision * recall, precision + recall),
+                "class_acc": recall, "pixel_acc": hit.sum() / max(cm.sum(), floor)}
+
     def compute_iou(self, per_class=True):
-        cm = self.confusion_matrix
-        intersection = np.diag(cm)
-        union = np.maximum(cm.sum(axis=1) + cm.sum(axis=0) - intersection, 1e-8)
-        iou = intersection / union
-        return iou if per_class else np.nanmean(iou)
+        v = self._ratios()["iou"]
+        return v if per_class else np.nanmean(v)
 
     def compute_dice(self, per_class=True):
-        cm = self.confusion_matrix
-        dice = 2 * np.diag(cm) / np.maximum(cm.sum(axis=1) + cm.sum(axis=0), 1e-8)
-        return dice if per_class else np.nanmean(dice)
+        v = self._ratios()["dice"]
+        return v if per_class else np.nanmean(v)
 
     def compute_pixel_accuracy(self):
-        cm = self.confusion_matrix
-        return np.diag(cm).sum() / max(cm.sum(), 1e-8)
+        return self._ratios()["pixel_acc"]
 
     def compute_mean_accuracy(self):
-        cm = self.confusion_matrix
-        return np.nanmean(np.diag(cm) / np.maximum(cm.sum(axis=1), 1e-8))
+        return np.nanmean(self._ratios()["class_acc"])
 
     def compute_precision_recall_f1(self, per_class=True):
-        cm = self.confusion_matrix
-        tp = np.diag(cm)
-        fp = cm.sum(axis=0) - tp
-        fn = cm.sum(axis=1) - tp
-        precision = tp / np.maximum(tp + fp, 1e-8)
-        recall = tp / np.maximum(tp + fn, 1e-8)
-        f1 = 2 * precision * recall / np.maximum(precision + recall, 1e-8)
-        if per_class:
-            return precision, recall, f1
-        return np.nanmean(precision), np.nanmean(recall), np.nanmean(f1)
+        r = self._ratios()
+        trio = (r["precision"], r["recall"], r["f1"])
+        return trio if per_class else tuple(np.nanmean(t) for t in trio)
 
     def compute_all_metrics(self):
-        metrics = {}
-        iou = self.compute_iou(per_class=True)
-        metrics["iou_per_class"] = iou
-        metrics["mean_iou"] = np.nanmean(iou)
-        dice = self.compute_dice(per_class=True)
-        metrics["dice_per_class"] = dice
-        metrics["mean_dice"] = np.nanmean(dice)
-        metrics["pixel_accuracy"] = self.compute_pixel_accuracy()
-        metrics["mean_accuracy"] = self.compute_mean_accuracy()
-        precision, recall, f1 = self.compute_precision_recall_f1(per_class=True)
-        metrics["precision_per_class"] = precision
-        metrics["recall_per_class"] = recall
-        metrics["f1_per_class"] = f1
-        metrics["mean_precision"] = np.nanmean(precision)
-        metrics["mean_recall"] = np.nanmean(recall)
-        metrics["mean_f1"] = np.nanmean(f1)
-        metrics["confusion_matrix"] = self.confusion_matrix
-        return metrics
+        r = self._ratios()
+        out = {"confusion_matrix": self.confusion_matrix, "pixel_accuracy": r["pixel_acc"],
+               "mean_accuracy": np.nanmean(r["class_acc"])}
+        for key, name in (("iou", "iou"), ("dice", "dice"), ("precision", "precision"), ("recall", "recall"), ("f1", "f1")):
+            out[f"{name}_per_class"] = r[key]
+            out[f"mean_{name}"] = np.nanmean(r[key])
+        return out
 
     def print_metrics(self, class_names=None):
         m = self.compute_all_metrics()
