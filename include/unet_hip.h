@@ -143,6 +143,20 @@ int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32_t w, const
                            const void* w_packed, int32_t c_out, void* y, float* partial, int32_t* n_parts,
                            void* stream);
 
+/* Data gradient of the SECOND convolution of DoubleConv (src/model.py:17) fused with the backward of the ReLU and
+ * the reduction half of the BatchNorm2d backward of the FIRST one (src/model.py:15-16), whose activation is this
+ * convolution's only input: dz = conv(dy, flipped W^T) * [fma(y_prev, bn_scale, bn_shift) > 0] (dense NHWC
+ * [n][h][w][c_dx], compute dtype) and partial[*n_parts][2][c_dx] = per-channel (sum dz, sum dz * (y_prev - bn_mean))
+ * of the stored dz, written by the kernel's epilogue -- feed both to unet_bn_bwd_premasked.  The (y, da) reduction pass
+ * of unet_bn_relu_bwd does not exist on this route.  w_packed = UNET_PACK_CONV_DGRAD [9][c_dx][c_dy]; partial capacity:
+ * unet_conv3x3_stats_max_parts(n, h, w) parts.  unet_conv3x3_dgrad_bnrelu_supported() says whether a shape is covered
+ * (bf16, 16-aligned frames, c_dy >= 128); otherwise use unet_conv3x3 + unet_bn_relu_bwd. */
+int32_t unet_conv3x3_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_dy, int32_t c_dx);
+int32_t unet_conv3x3_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy, int32_t c_dy,
+                                  const void* w_packed, int32_t c_dx, const void* y_prev, const float* bn_scale,
+                                  const float* bn_shift, const float* bn_mean, void* dz, float* partial,
+                                  int32_t* n_parts, void* stream);
+
 /* dW[co][ci][3][3] (fp32, OIHW) = sum over pixels of dY (x) shifted X; split-K over pixel
  * tiles with fp32 partial slabs in `workspace`, reduced in a fixed order (deterministic).
  * (autograd of nn.Conv2d, reached from total_loss.backward() at src/train_utils.py:132) */
@@ -191,6 +205,15 @@ int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t p
                          const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward when the producer of the gradient has already applied the ReLU mask in its own epilogue and left
+ * the two per-channel sums behind (unet_head_bnrelu_bwd, unet_conv3x3_dgrad_bnrelu): dz = da*[z>0] (compute dtype,
+ * NHWC), partial = fp32 [n_parts][2][c] holding sum dz and sum dz*(y - mean).  Ordered fp64 finalize -> dgamma, dbeta,
+ * then ONE pass dy = A*dz + B*y + K (dy may alias dz).  workspace: 3*c floats. */
+int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const void* y, int64_t pixels, int32_t c,
+                              const float* gamma, const float* save_mean, const float* save_istd,
+                              const float* partial, int32_t n_parts, float* dgamma, float* dbeta, void* dy,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- MaxPool2d(2) (src/model.py:32): stride 2, floor; first maximum wins ties ---------- */
 int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t c,
                           void* y, void* stream);
@@ -215,6 +238,22 @@ int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out, const floa
                       int32_t h, int32_t w, int32_t c_in, const float* weight, int32_t c_out,
                       int32_t sigmoid, void* dx, float* dweight, float* dbias, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* OutConv fed by the RAW convolution output y of the last conv-BatchNorm-ReLU layer (src/model.py:17-19 followed by
+ * :72 / :107 / :200,207): a = max(fma(y, bn_scale, bn_shift), 0) is formed on load -- the activation tensor is never
+ * written, its BatchNorm-apply pass does not exist.  bn_scale / bn_shift / bn_mean: outputs of
+ * unet_bn_finalize_partials.  The backward recomputes a for dweight, writes dz = da*[z>0] (NHWC compute dtype) and the
+ * BatchNorm-backward partial sums bn_partial[*n_parts][2][c_in] (capacity unet_head_bnrelu_max_parts() parts) for
+ * unet_bn_bwd_premasked: the (y, da) reduction pass does not exist either. */
+int32_t unet_head_bnrelu_fwd(int32_t dtype, const void* y, int32_t n, int32_t h, int32_t w, int32_t c_in,
+                             const float* bn_scale, const float* bn_shift, const float* weight, const float* bias,
+                             int32_t c_out, int32_t sigmoid, float* out, void* stream);
+size_t unet_head_bnrelu_max_parts(void);
+int32_t unet_head_bnrelu_bwd(int32_t dtype, const void* y, const float* bn_scale, const float* bn_shift,
+                             const float* bn_mean, const float* out, const float* dout, int32_t n, int32_t h, int32_t w,
+                             int32_t c_in, const float* weight, int32_t c_out, int32_t sigmoid, void* dz,
+                             float* dweight, float* dbias, float* bn_partial, int32_t* n_parts, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- loss heads (src/train_utils.py) ----------------------------------------------------- */
 size_t unet_loss_workspace(int64_t elems);

@@ -520,3 +520,235 @@ def test_conv3x3_fused_bn_statistics(hip, dtype, case):
     want_s, want_q = ys.double().sum((0, 2, 3)).cpu(), (ys.double() ** 2).sum((0, 2, 3)).cpu()
     assert float((sums[0] - want_s).abs().max()) < 1e-3 * max(1.0, float(want_s.abs().max()))
     assert float((sums[1] - want_q).abs().max()) < 1e-3 * max(1.0, float(want_q.abs().max()))
+
+
+# ------------------------------------------------------------------ BatchNorm fusions (round 2)
+def _bn_coefs(y, gamma, beta, eps=1e-5):
+    """mean, istd, scale, shift of training-mode BatchNorm2d over an NCHW fp32 tensor (fp64 arithmetic)."""
+    yd = y.double()
+    mean = yd.mean((0, 2, 3))
+    var = yd.var((0, 2, 3), unbiased=False)
+    istd = 1.0 / torch.sqrt(var + eps)
+    scale = gamma.double() * istd
+    shift = beta.double() - mean * scale
+    return mean.float(), istd.float(), scale.float(), shift.float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("co,sigmoid", [(1, True), (3, True), (4, False)])
+def test_head_fused_with_batchnorm_relu(hip, dtype, co, sigmoid):
+    """unet_head_bnrelu_fwd / _bwd + unet_bn_bwd_premasked (OutConv reading the RAW conv output: BatchNorm + ReLU on
+    load, ReLU mask + BatchNorm-backward sums in the head's backward) against torch autograd of
+    sigmoid(conv1x1(relu(batch_norm(y)))) on the same (dtype-rounded) y -- /root/reference/src/model.py:18-19,72,201."""
+    L, ops = hip
+    n, ci, h, w = 3, 64, 20, 24
+    y = rnd(f"hb_y{co}", (n, ci, h, w)) * 1.5 + 0.3
+    gamma, beta = rnd("hb_g", (ci,)) * 0.5 + 1.0, rnd("hb_b", (ci,)) * 0.2
+    wt, b = rnd(f"hb_w{co}", (co, ci, 1, 1)) * 0.2, rnd(f"hb_bias{co}", (co,)) * 0.1
+    g = rnd(f"hb_go{co}", (n, co, h, w))
+    yq = q(y, dtype).requires_grad_(True)
+    mean, istd, scale, shift = _bn_coefs(yq.detach(), gamma, beta)
+    gq, bq = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    # reference: activation rounded to the compute dtype like the stored activation of the unfused path
+    z = F.batch_norm(yq, None, None, gq, bq, True, 0.0, 1e-5)
+    a = torch.relu(z)
+    a_q = a + (q(a, dtype) - a).detach()
+    wq, bb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out_ref = F.conv2d(a_q, wq, bb)
+    if sigmoid:
+        out_ref = torch.sigmoid(out_ref)
+    out_ref.backward(g)
+    dt = ops._DT[dtype]
+    yd = nhwc(y, dtype)
+    coef = torch.stack([mean, istd, scale, shift]).to(dev())
+    wd, bd, gd = wt.to(dev()).contiguous(), b.to(dev()), g.to(dev()).contiguous()
+    out = torch.empty(n, co, h, w, device=dev())
+    L.check(L.lib().unet_head_bnrelu_fwd(dt, p(yd), n, h, w, ci, p(coef[2]), p(coef[3]), p(wd), p(bd), co, int(sigmoid),
+                                         p(out), st()), "head bnrelu fwd")
+    check(out, out_ref, dtype, "fused head fwd", f32=2e-5, bf=2e-3)
+    dz = ops._nhwc_empty(n, ci, h, w, dtype, dev())
+    dwh, dbh = torch.empty(co, ci, 1, 1, device=dev()), torch.empty(co, device=dev())
+    cap = L.lib().unet_head_bnrelu_max_parts()
+    part = torch.zeros(cap, 2, ci, device=dev())
+    nparts = C.c_int32(0)
+    need = L.lib().unet_head_bwd_workspace(n, h, w, ci, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_head_bnrelu_bwd(dt, p(yd), p(coef[2]), p(coef[3]), p(coef[0]), p(out), p(gd), n, h, w, ci, p(wd), co,
+                                         int(sigmoid), p(dz), p(dwh), p(dbh), p(part), C.byref(nparts), p(ws), need, st()),
+            "head bnrelu bwd")
+    assert 0 < nparts.value <= cap
+    check(dwh, wq.grad, dtype, "fused head dW", f32=5e-5, bf=5e-3)
+    check(dbh, bb.grad, dtype, "fused head db", f32=5e-5, bf=5e-3)
+    # the partial sums are sums over the dz the kernel stored
+    dzf = dz.float().cpu().double()
+    sums = part[:nparts.value].double().sum(0).cpu()
+    assert torch.allclose(sums[0], dzf.sum((0, 2, 3)), rtol=1e-4, atol=1e-3), "sum dz"
+    ref1 = (dzf * (yq.detach().double() - mean.double()[None, :, None, None])).sum((0, 2, 3))
+    assert torch.allclose(sums[1], ref1, rtol=1e-4, atol=1e-3), "sum dz*(y-mean)"
+    dgam, dbet = torch.empty(ci, device=dev()), torch.empty(ci, device=dev())
+    gam_d = gamma.to(dev())
+    ws3 = torch.empty(3 * ci * 4, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_bn_bwd_premasked(dt, p(dz), p(yd), n * h * w, ci, p(gam_d), p(coef[0]), p(coef[1]), p(part),
+                                          nparts.value, p(dgam), p(dbet), p(dz), p(ws3), ws3.numel(), st()), "bn premasked")
+    check(dgam, gq.grad, dtype, "dgamma", f32=1e-4, bf=2e-2)
+    check(dbet, bq.grad, dtype, "dbeta", f32=1e-4, bf=2e-2)
+    check(dz, yq.grad, dtype, "dy (in place)", f32=1e-4, bf=3e-2)
+
+
+DGRAD_BN_CASES = [  # n, c_dy, c_dx, h, w  -- the last two have > 256 work items per launch (persistent loop, block-mode sums)
+    (2, 128, 128, 16, 32), (1, 256, 64, 32, 16), (3, 128, 256, 16, 16), (8, 128, 128, 128, 128), (5, 128, 64, 64, 96)]
+
+
+@pytest.mark.parametrize("case", DGRAD_BN_CASES, ids=str)
+def test_conv3x3_dgrad_fused_relu_mask_and_bn_sums(hip, case):
+    """unet_conv3x3_dgrad_bnrelu + unet_bn_bwd_premasked against torch: dz = conv_transpose(dy) * [bn(y) > 0], the
+    two per-channel sums of the stored dz, then dy_prev / dgamma / dbeta of relu(batch_norm(y)) for that upstream
+    gradient (/root/reference/src/model.py:15-17 backward)."""
+    L, ops = hip
+    n, cy, cx, h, w = case
+    dtype = torch.bfloat16
+    dt = ops._DT[dtype]
+    assert L.lib().unet_conv3x3_dgrad_bnrelu_supported(dt, n, h, w, cy, cx) == 1
+    assert L.lib().unet_conv3x3_dgrad_bnrelu_supported(dt, n, h + 1, w, cy, cx) == 0
+    dy = rnd(f"db_dy{case}", (n, cy, h, w))
+    wt = rnd(f"db_w{case}", (cy, cx, 3, 3)) * (1.0 / (3 * cy ** 0.5))
+    y = rnd(f"db_y{case}", (n, cx, h, w)) * 1.3 + 0.2
+    gamma, beta = rnd("db_g", (cx,)) * 0.5 + 1.0, rnd("db_b", (cx,)) * 0.3
+    dyq, wq, yq = q(dy, dtype), q(wt, dtype), q(y, dtype)
+    mean, istd, scale, shift = _bn_coefs(yq, gamma, beta)
+    da_ref = F.conv_transpose2d(dyq, wq, padding=1)                    # data gradient of conv2d(x, wt, padding=1)
+    on = torch.addcmul(shift[None, :, None, None], yq, scale[None, :, None, None]) > 0   # ~ fma; ties have measure 0
+    dz_ref = da_ref * on
+    wd = wt.to(dev())
+    wpd = ops.pack_weight(wd, L.PACK_CONV_DGRAD, cx, cy, dtype)
+    dyd, yd = nhwc(dy, dtype), nhwc(y, dtype)
+    coef = torch.stack([mean, istd, scale, shift]).to(dev())
+    dz = ops._nhwc_empty(n, cx, h, w, dtype, dev())
+    cap = L.lib().unet_conv3x3_stats_max_parts(n, h, w)
+    part = torch.zeros(cap, 2, cx, device=dev())
+    nparts = C.c_int32(0)
+    L.check(L.lib().unet_conv3x3_dgrad_bnrelu(dt, n, h, w, p(dyd), cy, p(wpd), cx, p(yd), p(coef[2]), p(coef[3]), p(coef[0]),
+                                              p(dz), p(part), C.byref(nparts), st()), "dgrad bnrelu")
+    assert 0 < nparts.value <= cap
+    # mask decisions can differ from the reference only where |scale*y+shift| is at rounding level: compare away from 0
+    zabs = torch.addcmul(shift[None, :, None, None], yq, scale[None, :, None, None]).abs()
+    safe = zabs > 1e-4
+    err = ((dz.float().cpu() - dz_ref) * safe).abs().max()
+    assert float(err) <= 1.2e-2 * max(1.0, float(dz_ref.abs().max())), f"dz: max err {float(err):.3e}"
+    assert float((~safe).float().mean()) < 1e-3
+    # unfused route through the same library: identical kernels up to the epilogue -> dz must match bit for bit
+    da2 = ops._nhwc_empty(n, cx, h, w, dtype, dev())
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(dyd, 0, 0), None]), p(wpd), cx, views(L, [(da2, 0, 0), None]), cx, 0,
+                                 L.K_CONV_DGRAD, st()), "dgrad plain")
+    on_d = torch.addcmul(coef[3][None, :, None, None], yd.float(), coef[2][None, :, None, None]) > 0
+    agree = (dz.float() == da2.float() * on_d).float().mean()
+    assert float(agree) > 0.9999, f"fused vs unfused dz agree on {float(agree):.6f}"
+    dzf = dz.float().cpu().double()
+    sums = part[:nparts.value].double().sum(0).cpu()
+    assert torch.allclose(sums[0], dzf.sum((0, 2, 3)), rtol=2e-4, atol=2e-2), "sum dz"
+    ref1 = (dzf * (yq.double() - mean.double()[None, :, None, None])).sum((0, 2, 3))
+    assert torch.allclose(sums[1], ref1, rtol=2e-4, atol=2e-2), "sum dz*(y-mean)"
+    # second half: dy_prev, dgamma, dbeta vs autograd of relu(bn(y)) fed with the kernel's own (unmasked) gradient
+    yr = yq.clone().requires_grad_(True)
+    gq, bq = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.relu(F.batch_norm(yr, None, None, gq, bq, True, 0.0, 1e-5)).backward(da2.float().cpu())
+    dgam, dbet = torch.empty(cx, device=dev()), torch.empty(cx, device=dev())
+    ws3 = torch.empty(3 * cx * 4, dtype=torch.uint8, device=dev())
+    out = ops._nhwc_empty(n, cx, h, w, dtype, dev())
+    L.check(L.lib().unet_bn_bwd_premasked(dt, p(dz), p(yd), n * h * w, cx, p(gamma.to(dev())), p(coef[0]), p(coef[1]),
+                                          p(part), nparts.value, p(dgam), p(dbet), p(out), p(ws3), ws3.numel(), st()),
+            "bn premasked")
+    check(dgam, gq.grad, dtype, "dgamma", bf=5e-3)
+    check(dbet, bq.grad, dtype, "dbeta", bf=5e-3)
+    check(out, yr.grad, dtype, "dy_prev", bf=1.5e-2)
+    # determinism: ordered partials
+    part2 = torch.zeros_like(part)
+    dz2 = torch.empty_like(dz)
+    L.check(L.lib().unet_conv3x3_dgrad_bnrelu(dt, n, h, w, p(dyd), cy, p(wpd), cx, p(yd), p(coef[2]), p(coef[3]), p(coef[0]),
+                                              p(dz2), p(part2), C.byref(nparts), st()), "dgrad bnrelu again")
+    assert torch.equal(dz, dz2) and torch.equal(part, part2)
+
+
+BIG_CONV_CASES = [  # > 256 work items of the persistent LDS-DMA kernels (the benchmark's code path), vs F.conv2d on the CPU
+    # n, cin, cout, h, w
+    (8, 128, 128, 128, 128),    # pdma128: 512 items, block-mode statistics (tiles % 256 == 0)
+    (5, 128, 128, 64, 96),      # pdma128: 120 tiles -> per-tile statistics... and a partial last round
+    (5, 128, 64, 128, 128),     # pdma64: 320 items, per-tile statistics
+    (4, 256, 64, 128, 128),     # pdma64: 256 items per channel tile, block mode
+]
+
+
+@pytest.mark.parametrize("case", BIG_CONV_CASES, ids=str)
+def test_conv3x3_persistent_kernels_many_work_items(hip, case):
+    """The multi-work-item path of conv3_pdma{128,64}_kernel (cross-item DMA continuation, after-epilogue vmcnt counts,
+    block-mode BatchNorm partials) against F.conv2d: forward + fused statistics, data gradient with and without
+    accumulate, weight gradient.  These are the shapes class bench.py runs; every smaller case has <= 18 items."""
+    L, ops = hip
+    n, ci, co, h, w = case
+    dtype = torch.bfloat16
+    dt = ops._DT[dtype]
+    x = rnd(f"big_x{case}", (n, ci, h, w))
+    wt = rnd(f"big_w{case}", (co, ci, 3, 3)) * (1.0 / (3 * ci ** 0.5))
+    gy = rnd(f"big_g{case}", (n, co, h, w))
+    xq, wq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), q(gy, dtype)
+    ref = F.conv2d(xq, wq, padding=1)
+    ref.backward(gq)
+    xd, gd, wd = nhwc(x, dtype), nhwc(gy, dtype), wt.to(dev())
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wd, L.PACK_CONV_FWD, co, ci, dtype)
+    cap = L.lib().unet_conv3x3_stats_max_parts(n, h, w)
+    part = torch.zeros(cap * 2 * co, device=dev())
+    nparts = C.c_int32(0)
+    L.check(L.lib().unet_conv3x3_stats(dt, n, h, w, views(L, [(xd, 0, 0), None]), p(wp), co, p(y), p(part), C.byref(nparts),
+                                       st()), "conv stats")
+    check(y, ref, dtype, "conv3x3 fwd (many work items)")
+    sums = part[:nparts.value * 2 * co].view(nparts.value, 2, co).double().sum(0).cpu()
+    yf = y.float().cpu().double()
+    assert torch.allclose(sums[0], yf.sum((0, 2, 3)), rtol=2e-4, atol=5e-2), "fused sum(y)"
+    assert torch.allclose(sums[1], (yf * yf).sum((0, 2, 3)), rtol=2e-4, atol=5e-2), "fused sum(y^2)"
+    y_plain = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(xd, 0, 0), None]), p(wp), co, views(L, [(y_plain, 0, 0), None]),
+                                 co, 0, L.K_CONV_FWD, st()), "conv fwd")
+    assert torch.equal(y, y_plain)
+    dx = ops._nhwc_empty(n, ci, h, w, dtype, dev())
+    wpd = ops.pack_weight(wd, L.PACK_CONV_DGRAD, ci, co, dtype)
+    if co >= 128:     # the data gradient of a layer with >= 128 output channels runs on the persistent kernels too
+        L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), ci, views(L, [(dx, 0, 0), None]),
+                                     ci, 0, L.K_CONV_DGRAD, st()), "conv dgrad")
+        check(dx, xq.grad, dtype, "conv3x3 dgrad (many work items)")
+        L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), ci, views(L, [(dx, 0, 0), None]),
+                                     ci, 1, L.K_CONV_DGRAD, st()), "conv dgrad acc")
+        check(dx, 2 * xq.grad, dtype, "conv3x3 dgrad accumulate (many work items)", bf=2.5e-2)
+    dw = torch.empty(co, ci, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, views(L, [(xd, 0, 0), None]), p(gd), co, p(dw), ci, p(ws), need, st()),
+            "conv wgrad")
+    check(dw, wq.grad, dtype, "conv3x3 wgrad (many work items)", bf=5e-3)
+
+
+def test_conv3x3_persistent_two_source_many_work_items(hip):
+    """Skip-concat form (two source views, src/model.py:65) on the persistent kernel with > 256 work items, and its
+    two-destination data gradient."""
+    L, ops = hip
+    dtype = torch.bfloat16
+    dt = ops._DT[dtype]
+    n, c0, c1, co, h, w = 6, 64, 64, 128, 112, 128
+    x2, x1 = rnd("b2_x2", (n, c0, h, w)), rnd("b2_x1", (n, c1, h, w))
+    wt = rnd("b2_w", (co, c0 + c1, 3, 3)) * 0.03
+    gy = rnd("b2_g", (n, co, h, w))
+    x2q, x1q, wq = q(x2, dtype).requires_grad_(True), q(x1, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True)
+    ref = F.conv2d(torch.cat([x2q, x1q], 1), wq, padding=1)
+    ref.backward(q(gy, dtype))
+    x2d, x1d, gd, wd = nhwc(x2, dtype), nhwc(x1, dtype), nhwc(gy, dtype), wt.to(dev())
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wd, L.PACK_CONV_FWD, co, c0 + c1, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(x2d, 0, 0), (x1d, 0, 0)]), p(wp), co, views(L, [(y, 0, 0), None]), co, 0,
+                                 L.K_CONV_FWD, st()), "conv fwd 2 src")
+    check(y, ref, dtype, "two-source conv fwd (many work items)")
+    d2, d1 = ops._nhwc_empty(n, c0, h, w, dtype, dev()), ops._nhwc_empty(n, c1, h, w, dtype, dev())
+    wpd = ops.pack_weight(wd, L.PACK_CONV_DGRAD, c0 + c1, co, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), c0 + c1, views(L, [(d2, 0, 0), (d1, 0, 0)]),
+                                 c0, 0, L.K_CONV_DGRAD, st()), "conv dgrad 2 dst")
+    check(d2, x2q.grad, dtype, "two-destination dgrad, skip half")
+    check(d1, x1q.grad, dtype, "two-destination dgrad, up half")

@@ -51,6 +51,8 @@ SIGNATURES = {
     "unet_conv3x3_first_wgrad_workspace": (_z, [_i, _i, _i]),
     "unet_conv3x3_first_wgrad": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
     "unet_bn_finalize_partials": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
+    "unet_conv3x3_dgrad_bnrelu_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_conv3x3_dgrad_bnrelu": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "unet_conv3x3_wgrad_workspace": (_z, [_i, _i, _i, _i, _i]),
     "unet_conv3x3_wgrad": (_i, [_i, _i, _i, _i, C.POINTER(View), _p, _i, _p, _i, _p, _z, _p]),
     "unet_convt2x2_fwd": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p]),
@@ -62,6 +64,10 @@ SIGNATURES = {
     "unet_bn_eval_coeffs": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "unet_bn_relu_apply": (_i, [_i, _p, _l, _i, _p, _p, _p, _p]),
     "unet_bn_relu_bwd": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "unet_bn_bwd_premasked": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
+    "unet_head_bnrelu_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "unet_head_bnrelu_max_parts": (_z, []),
+    "unet_head_bnrelu_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "unet_maxpool2_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_maxpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "unet_upsample_bilinear2x_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),

@@ -88,17 +88,36 @@ constexpr int FL = 16, FC = 16;
 template <int TL, int TC>
 __device__ inline void sum_parts_t(const float* part, int nparts, int C, int c, int rl, double (&red)[2][TL][TC],
                                    double& a, double& b) {
+  // lane rl takes partials rl, rl+TL, ... (independent loads), then a FIXED binary tree over the TL lanes through LDS
+  // (log2(TL) steps instead of one thread walking TL doubles: these kernels are pure latency)
   double s0 = 0.0, s1 = 0.0;
-  for (int k = rl; k < nparts; k += TL) {
+  int k = rl;
+  for (; k + 3 * TL < nparts; k += 4 * TL) {
+    const float a0 = part[((size_t)k * 2 + 0) * C + c], b0 = part[((size_t)k * 2 + 1) * C + c];
+    const float a1 = part[((size_t)(k + TL) * 2 + 0) * C + c], b1 = part[((size_t)(k + TL) * 2 + 1) * C + c];
+    const float a2 = part[((size_t)(k + 2 * TL) * 2 + 0) * C + c], b2 = part[((size_t)(k + 2 * TL) * 2 + 1) * C + c];
+    const float a3 = part[((size_t)(k + 3 * TL) * 2 + 0) * C + c], b3 = part[((size_t)(k + 3 * TL) * 2 + 1) * C + c];
+    s0 += (double)a0; s0 += (double)a1; s0 += (double)a2; s0 += (double)a3;
+    s1 += (double)b0; s1 += (double)b1; s1 += (double)b2; s1 += (double)b3;
+  }
+  for (; k < nparts; k += TL) {
     s0 += (double)part[((size_t)k * 2 + 0) * C + c];
     s1 += (double)part[((size_t)k * 2 + 1) * C + c];
   }
-  red[0][rl][c % TC] = s0;
-  red[1][rl][c % TC] = s1;
+  const int cc = c % TC;
+  red[0][rl][cc] = s0;
+  red[1][rl][cc] = s1;
   __syncthreads();
-  a = 0.0; b = 0.0;
 #pragma unroll
-  for (int i = 0; i < TL; ++i) { a += red[0][i][c % TC]; b += red[1][i][c % TC]; }
+  for (int st = TL / 2; st >= 1; st >>= 1) {
+    if (rl < st) {
+      red[0][rl][cc] += red[0][rl + st][cc];
+      red[1][rl][cc] += red[1][rl + st][cc];
+    }
+    __syncthreads();
+  }
+  a = red[0][0][cc];
+  b = red[1][0][cc];
 }
 __device__ inline void sum_parts(const float* part, int nparts, int C, int c, int rl, double (&red)[2][FL][FC],
                                  double& a, double& b) {
@@ -141,12 +160,13 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ istd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coefs) {
+                                                              float* __restrict__ coefs, int raw) {
   __shared__ double red[2][TL][TC];
   const int c = blockIdx.x * TC + (threadIdx.x % TC), rl = threadIdx.x / TC;
   double s, ss;
   sum_parts_t<TL, TC>(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
+  if (raw) ss *= (double)istd[c];          // partials hold sum dz * (y - mean): normalise here
   const float db = (float)s, dg = (float)ss;
   dbeta[c] = db;
   dgamma[c] = dg;
@@ -274,6 +294,59 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
         const int c = c0 + j;
         const float d = fmaf(v[j], scale[c], shift[c]) > 0.f ? g[j] : 0.f;
         g[j] = fmaf(coefs[c], d, fmaf(coefs[C + c], v[j], coefs[2 * C + c]));
+      }
+      Vec<T>::store(dy + i * PIECE, g);
+    }
+  }
+}
+
+// dy = A*dz + B*y + K for a gradient that already carries the ReLU mask (dz written by the producer's epilogue:
+// head_bwd_kernel<BN>, conv dgrad with fused mask).  dy may alias dz (element-wise in place).
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void bn_bwd_apply_premasked_kernel(const T* dz, const T* __restrict__ y,
+                                                                     long long pieces, int C,
+                                                                     const float* __restrict__ coefs, T* dy) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (FAST) {
+    const int c0 = (threadIdx.x * PIECE) % C;
+    float A[PIECE], B[PIECE], K[PIECE];
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) { A[j] = coefs[c0 + j]; B[j] = coefs[C + c0 + j]; K[j] = coefs[2 * C + c0 + j]; }
+    for (; i + 3 * stride < pieces; i += 4 * stride) {
+      float v[4][PIECE], g[4][PIECE];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        Vec<T>::load(y + (i + u * stride) * PIECE, v[u]);
+        Vec<T>::load(dz + (i + u * stride) * PIECE, g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) g[u][j] = fmaf(A[j], g[u][j], fmaf(B[j], v[u][j], K[j]));
+        Vec<T>::store(dy + (i + u * stride) * PIECE, g[u]);
+      }
+    }
+    for (; i < pieces; i += stride) {
+      float v[PIECE], g[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+      Vec<T>::load(dz + i * PIECE, g);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) g[j] = fmaf(A[j], g[j], fmaf(B[j], v[j], K[j]));
+      Vec<T>::store(dy + i * PIECE, g);
+    }
+  } else {
+    const int groups = C / PIECE;
+    for (; i < pieces; i += stride) {
+      const int c0 = (int)(i % groups) * PIECE;
+      float v[PIECE], g[PIECE];
+      Vec<T>::load(y + i * PIECE, v);
+      Vec<T>::load(dz + i * PIECE, g);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        const int c = c0 + j;
+        g[j] = fmaf(coefs[c], g[j], fmaf(coefs[C + c], v[j], coefs[2 * C + c]));
       }
       Vec<T>::store(dy + i * PIECE, g);
     }
@@ -448,10 +521,10 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
   const float inv = (float)(1.0 / (double)pixels);
   if (pl.nparts >= 128)      // latency-bound: 64 partial-lanes per channel
     hipLaunchKernelGGL((bn_finalize_bwd_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
-                       save_mean, save_istd, dgamma, dbeta, coefs);
+                       save_mean, save_istd, dgamma, dbeta, coefs, 0);
   else
     hipLaunchKernelGGL((bn_finalize_bwd_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
-                       save_mean, save_istd, dgamma, dbeta, coefs);
+                       save_mean, save_istd, dgamma, dbeta, coefs, 0);
   rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
   if (dtype == UNET_BF16) {
@@ -472,4 +545,48 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
                          (const float*)da, (const float*)y, pieces, c, scale, shift, coefs, (float*)dy);
   }
   return unet_check_launch("bn_relu_bwd_apply_kernel");
+}
+
+extern "C" int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const void* y, int64_t pixels, int32_t c,
+                                         const float* gamma, const float* save_mean, const float* save_istd,
+                                         const float* partial, int32_t n_parts, float* dgamma, float* dbeta, void* dy,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(dz && y && gamma && save_mean && save_istd && partial && dgamma && dbeta && dy && workspace,
+               UNET_ERR_BAD_ARG, "unet_bn_bwd_premasked: null pointer");
+  UNET_REQUIRE(pixels > 0 && c > 0 && c % FC == 0 && n_parts > 0, UNET_ERR_UNSUPPORTED, "unet_bn_bwd_premasked: c=%d", c);
+  UNET_REQUIRE(workspace_bytes >= (size_t)3 * c * sizeof(float), UNET_ERR_WORKSPACE,
+               "unet_bn_bwd_premasked: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s);
+  float* coefs = (float*)workspace;
+  const float inv = (float)(1.0 / (double)pixels);
+  if (n_parts >= 128)
+    hipLaunchKernelGGL((bn_finalize_bwd_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, partial, n_parts, c, inv, gamma,
+                       save_mean, save_istd, dgamma, dbeta, coefs, 1);
+  else
+    hipLaunchKernelGGL((bn_finalize_bwd_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, partial, n_parts, c, inv, gamma,
+                       save_mean, save_istd, dgamma, dbeta, coefs, 1);
+  int32_t rc = unet_check_launch("bn_finalize_bwd_kernel");
+  if (rc) return rc;
+  if (dtype == UNET_BF16) {
+    const long long pieces = pixels * c / 8;
+    if ((256 * 8) % c == 0)
+      hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<bf16_t, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<bf16_t, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy);
+  } else if (dtype == UNET_F32) {
+    const long long pieces = pixels * c / 4;
+    if ((256 * 4) % c == 0)
+      hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<float, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<float, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
+                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy);
+  } else {
+    unet_set_error("unet_bn_bwd_premasked: dtype %d", dtype);
+    return UNET_ERR_BAD_ARG;
+  }
+  return unet_check_launch("bn_bwd_apply_premasked_kernel");
 }

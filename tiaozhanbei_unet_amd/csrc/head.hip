@@ -29,11 +29,15 @@ __device__ __forceinline__ void split_pixel(long long p, long long hw, long long
 // each, a pixel's NHWC row is one contiguous read / write), S = TPP sub-steps cover the 64 pixels and their loads
 // are all in flight together.  Phase 2: lane = pixel, so the NCHW fp32 planes (out, dout) are read and written as
 // 256 contiguous bytes per wave -- lanes trade values between the two layouts with wave shuffles.
-template <typename T, int TPP, int CO>
+// BN: x is the RAW convolution output y of the preceding conv-BatchNorm-ReLU layer; a = max(fma(y, scale, shift), 0),
+// rounded to T like the stored activation would be, is formed on load (the activation tensor is never written).
+template <typename T, int TPP, int CO, bool BN = false>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long long pixels, long long hw,
                                                        int Cin, const float* __restrict__ w,
                                                        const float* __restrict__ b, int sigm,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out,
+                                                       const float* __restrict__ bn_scale = nullptr,
+                                                       const float* __restrict__ bn_shift = nullptr) {
   constexpr int PIECE = ET<T>::PIECE;
   constexpr int PPW = 64 / TPP, S = TPP;
   constexpr int SB = S < 8 ? S : 8;              // sub-steps whose loads are in flight together (register budget)
@@ -44,6 +48,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
   for (int co = 0; co < CO; ++co)
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) wr[co][j] = w[co * Cin + g * PIECE + j];
+  float sc[BN ? PIECE : 1], sh[BN ? PIECE : 1];
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) { sc[j] = bn_scale[g * PIECE + j]; sh[j] = bn_shift[g * PIECE + j]; }
+  }
   const long long nw = (long long)gridDim.x * 4;
   for (long long c = blockIdx.x * 4LL + wave; c * 64 < pixels; c += nw) {
     const long long base = c * 64;
@@ -59,6 +68,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < PIECE; ++j) v[i][j] = 0.f;
         if (p < pixels) Vec<T>::load(x + p * Cin + g * PIECE, v[i]);
+      }
+      if constexpr (BN) {
+#pragma unroll
+        for (int i = 0; i < SB; ++i)
+#pragma unroll
+          for (int j = 0; j < PIECE; ++j)
+            v[i][j] = ET<T>::to_f(ET<T>::from_f(fmaxf(fmaf(v[i][j], sc[j], sh[j]), 0.f)));
       }
 #pragma unroll
       for (int i = 0; i < SB; ++i) {
@@ -96,11 +112,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int TPP, int CO>
+// BN: x is the raw convolution output y (see head_fwd_kernel): the activation is recomputed for the weight gradient,
+// the gradient w.r.t. the activation gets the ReLU mask at once (dx = dz = da * [fma(y, scale, shift) > 0], rounded to
+// T) and the two per-channel sums the BatchNorm backward needs -- sum dz and sum dz * (y - mean) of the ROUNDED dz --
+// leave as one ordered partial per block (bn_part[block][2][Cin]): no separate reduction pass over (y, da).
+template <typename T, int TPP, int CO, bool BN = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ out,
                                                        const float* __restrict__ dout, long long pixels,
                                                        long long hw, int Cin, const float* __restrict__ w,
-                                                       int sigm, T* __restrict__ dx, float* __restrict__ part) {
+                                                       int sigm, T* __restrict__ dx, float* __restrict__ part,
+                                                       const float* __restrict__ bn_scale = nullptr,
+                                                       const float* __restrict__ bn_shift = nullptr,
+                                                       const float* __restrict__ bn_mean = nullptr,
+                                                       float* __restrict__ bn_part = nullptr) {
   constexpr int PIECE = ET<T>::PIECE;
   constexpr int PPW = 64 / TPP, S = TPP;
   __shared__ float red[4][MAXCO * 129];
@@ -117,6 +141,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     dbacc[co] = 0.f;
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) dwacc[co][j] = 0.f;
+  }
+  float sc[BN ? PIECE : 1], sh[BN ? PIECE : 1], mu[BN ? PIECE : 1], bs0[BN ? PIECE : 1], bs1[BN ? PIECE : 1];
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) {
+      sc[j] = bn_scale[g * PIECE + j]; sh[j] = bn_shift[g * PIECE + j]; mu[j] = bn_mean[g * PIECE + j];
+      bs0[j] = 0.f; bs1[j] = 0.f;
+    }
   }
   constexpr int SB = S < 8 ? S : 8;              // sub-steps whose loads are in flight together (register budget)
   const long long nw = (long long)gridDim.x * 4;
@@ -159,13 +191,34 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         for (int co = 0; co < CO; ++co) ds[co] = __shfl(dl[co], s * PPW + sub);
 #pragma unroll
         for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+        float av[PIECE];                       // the activation the 1x1 filter saw
+        bool on[PIECE];
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) {
+          if constexpr (BN) {
+            const float z = fmaf(v[i][j], sc[j], sh[j]);
+            on[j] = z > 0.f;
+            av[j] = ET<T>::to_f(ET<T>::from_f(fmaxf(z, 0.f)));
+          } else {
+            on[j] = true;
+            av[j] = v[i][j];
+          }
+        }
 #pragma unroll
         for (int co = 0; co < CO; ++co)
 #pragma unroll
           for (int j = 0; j < PIECE; ++j) {
             d[j] = fmaf(ds[co], wr[co][j], d[j]);
-            dwacc[co][j] = fmaf(ds[co], v[i][j], dwacc[co][j]);      // v is 0 and ds is 0 past the end
+            dwacc[co][j] = fmaf(ds[co], av[j], dwacc[co][j]);        // ds is 0 past the end
           }
+        if constexpr (BN) {
+#pragma unroll
+          for (int j = 0; j < PIECE; ++j) {
+            d[j] = ET<T>::to_f(ET<T>::from_f(on[j] ? d[j] : 0.f));     // dz as stored
+            bs0[j] += d[j];
+            bs1[j] = fmaf(d[j], v[i][j] - mu[j], bs1[j]);
+          }
+        }
         if (p < pixels) Vec<T>::store(dx + p * Cin + g * PIECE, d);
       }
     }
@@ -194,6 +247,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   // part[block][co][Cin+1]  (last column = bias gradient)
   for (int i = threadIdx.x; i < CO * stride; i += 256)
     part[(size_t)blockIdx.x * CO * stride + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  if constexpr (BN) {
+#pragma unroll
+    for (int m = TPP; m < 64; m <<= 1)
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        bs0[j] += __shfl_xor(bs0[j], m);
+        bs1[j] += __shfl_xor(bs1[j], m);
+      }
+    __syncthreads();                               // the weight-gradient partials above are consumed
+    if (lane < TPP) {
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        red[wave][lane * PIECE + j] = bs0[j];
+        red[wave][Cin + lane * PIECE + j] = bs1[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cin; i += 256)   // bn_part[block][2][Cin], fixed order
+      bn_part[(size_t)blockIdx.x * 2 * Cin + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
 }
 
 // one block per output element group: 256 threads sum the block partials of 4 outputs (64 lanes each)
@@ -302,6 +375,76 @@ extern "C" int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out,
   }
   int32_t rc = unet_check_launch("head_bwd_kernel");
   if (rc) return rc;
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(c_out * (c_in + 1), 4)), dim3(256), 0, s,
+                     (const float*)workspace, nb, c_out, c_in, dweight, dbias);
+  return unet_check_launch("head_bwd_finalize_kernel");
+}
+
+// ---- OutConv fed by the RAW convolution output of the last conv-BatchNorm-ReLU layer (src/model.py:17-19 -> :72) ----
+extern "C" int32_t unet_head_bnrelu_fwd(int32_t dtype, const void* y, int32_t n, int32_t h, int32_t w, int32_t c_in,
+                                        const float* bn_scale, const float* bn_shift, const float* weight,
+                                        const float* bias, int32_t c_out, int32_t sigmoid, float* out, void* stream) {
+  UNET_REQUIRE(y && bn_scale && bn_shift && weight && bias && out, UNET_ERR_BAD_ARG, "unet_head_bnrelu_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_head_bnrelu_fwd: bad dims");
+  UNET_REQUIRE(c_out >= 1 && c_out <= MAXCO && (c_in == 32 || c_in == 64 || c_in == 128), UNET_ERR_UNSUPPORTED,
+               "unet_head_bnrelu_fwd: %d -> %d channels unsupported (c_out <= 8, c_in in {32,64,128})", c_in, c_out);
+  UNET_REQUIRE(c_out <= c_in / (dtype == UNET_BF16 ? 8 : 4), UNET_ERR_UNSUPPORTED,
+               "unet_head_bnrelu_fwd: c_out %d too wide for c_in %d", c_out, c_in);
+  hipStream_t s = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w, hw = (long long)h * w;
+  ProfScope prof(UNET_K_HEAD, 2.0 * pixels * c_in * c_out, s);
+  if (dtype == UNET_BF16) {
+    const int tpp = tpp_of<bf16_t>(c_in);
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_fwd_kernel<bf16_t, TPP, CO, true>), dim3(head_blocks(pixels, TPP)),
+                    dim3(256), 0, s, (const bf16_t*)y, pixels, hw, c_in, weight, bias, sigmoid, out, bn_scale, bn_shift));
+  } else if (dtype == UNET_F32) {
+    const int tpp = tpp_of<float>(c_in);
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_fwd_kernel<float, TPP, CO, true>), dim3(head_blocks(pixels, TPP)),
+                    dim3(256), 0, s, (const float*)y, pixels, hw, c_in, weight, bias, sigmoid, out, bn_scale, bn_shift));
+  } else {
+    unet_set_error("unet_head_bnrelu_fwd: dtype %d", dtype);
+    return UNET_ERR_BAD_ARG;
+  }
+  return unet_check_launch("head_fwd_kernel<BN>");
+}
+
+extern "C" size_t unet_head_bnrelu_max_parts(void) { return 1024; }
+
+extern "C" int32_t unet_head_bnrelu_bwd(int32_t dtype, const void* y, const float* bn_scale, const float* bn_shift,
+                                        const float* bn_mean, const float* out, const float* dout, int32_t n, int32_t h,
+                                        int32_t w, int32_t c_in, const float* weight, int32_t c_out, int32_t sigmoid,
+                                        void* dz, float* dweight, float* dbias, float* bn_partial, int32_t* n_parts,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(y && bn_scale && bn_shift && bn_mean && dout && weight && dz && dweight && dbias && bn_partial && n_parts &&
+               workspace && (out || !sigmoid), UNET_ERR_BAD_ARG, "unet_head_bnrelu_bwd: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_head_bnrelu_bwd: bad dims");
+  UNET_REQUIRE(c_out >= 1 && c_out <= MAXCO && (c_in == 32 || c_in == 64 || c_in == 128), UNET_ERR_UNSUPPORTED,
+               "unet_head_bnrelu_bwd: %d -> %d channels unsupported", c_in, c_out);
+  UNET_REQUIRE(workspace_bytes >= unet_head_bwd_workspace(n, h, w, c_in, c_out), UNET_ERR_WORKSPACE,
+               "unet_head_bnrelu_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w, hw = (long long)h * w;
+  ProfScope prof(UNET_K_HEAD, 4.0 * pixels * c_in * c_out, s);
+  int nb = 0;
+  if (dtype == UNET_BF16) {
+    const int tpp = tpp_of<bf16_t>(c_in);
+    nb = head_blocks(pixels, tpp);
+    HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP, CO, true>), dim3(nb), dim3(256), 0, s,
+                    (const bf16_t*)y, out, dout, pixels, hw, c_in, weight, sigmoid, (bf16_t*)dz, (float*)workspace,
+                    bn_scale, bn_shift, bn_mean, bn_partial));
+  } else if (dtype == UNET_F32) {
+    const int tpp = tpp_of<float>(c_in);
+    nb = head_blocks(pixels, tpp);
+    HEAD_TPP_SWITCH(float, tpp, hipLaunchKernelGGL((head_bwd_kernel<float, TPP, CO, true>), dim3(nb), dim3(256), 0, s,
+                    (const float*)y, out, dout, pixels, hw, c_in, weight, sigmoid, (float*)dz, (float*)workspace,
+                    bn_scale, bn_shift, bn_mean, bn_partial));
+  } else {
+    unet_set_error("unet_head_bnrelu_bwd: dtype %d", dtype);
+    return UNET_ERR_BAD_ARG;
+  }
+  int32_t rc = unet_check_launch("head_bwd_kernel<BN>");
+  if (rc) return rc;
+  *n_parts = nb;
   hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(c_out * (c_in + 1), 4)), dim3(256), 0, s,
                      (const float*)workspace, nb, c_out, c_in, dweight, dbias);
   return unet_check_launch("head_bwd_finalize_kernel");

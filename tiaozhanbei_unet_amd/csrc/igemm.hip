@@ -46,6 +46,14 @@ struct IgemmParams {
   int zdiv;         // > 0: GEMM row = z*zdiv + co (convT fwd as one GEMM with 4*Cout rows)
   float* stats;     // != NULL: per-block BatchNorm partials [part][2][Cout] written by the epilogue
   int tilesX, tilesY, nCo;
+  // data gradient fused with the ReLU mask + BatchNorm-backward sums of the layer that PRODUCED this convolution's
+  // input (kernels instantiated with BNBWD): bn_y = that layer's raw conv output [N][H][W][Cout] (same geometry as
+  // dst[0]), bn_scale / bn_shift / bn_mean = its forward coefficients.  The epilogue stores dz = dx * [fma(y, scale,
+  // shift) > 0] and the partial sums (sum dz, sum dz * (y - mean)) go where the forward statistics would (stats).
+  const char* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -902,7 +910,7 @@ struct CfgP {
   static constexpr int NST = CT / 2 * 4;                             // 16-byte output stores per lane per work item
 };
 
-template <int BN>
+template <int BN, bool BNBWD = false>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   using C = CfgP<BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1129,6 +1137,70 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+    if constexpr (BNBWD) {
+      // dgrad + ReLU mask + BatchNorm-backward sums of the producing layer.  dst[0] is dense and frame-sized, so the
+      // store offset of a (pixel, tile pair) is also the offset of its 8 y values; y comes in with the same 16-byte
+      // loads as the gradient fan-in's old values and is un-swapped to the accumulator layout.  ALL loads of the work
+      // item are issued before the first use: one exposed memory round trip per item.
+      const DViewW D = P.dst[0];
+      const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
+      const __amdgpu_buffer_rsrc_t yrs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(P.bn_y + (size_t)n * dimg), (short)0, (int)dimg, 0x00020000);
+      u32x4 yraw[4][C::CT / 2];
+      f32x4 csc[C::CT / 2][2], csh[C::CT / 2][2], cmu[C::CT / 2][2];
+      unsigned vo4[4][C::CT / 2];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
+        const bool ok = fy < P.H && fx < P.W;
+#pragma unroll
+        for (int cp = 0; cp < C::CT / 2; ++cp) {
+          const int cw = co0 + wco * (BN / 2) + cp * 32;
+          const int co = cw + (kb & 1) * 16 + (kb >> 1) * 8;
+          vo4[pt][cp] = ok ? (unsigned)(((fy * D.W + fx) * D.C + co) * 2) : OOB;
+          yraw[pt][cp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, vo4[pt][cp], 0, 0);
+        }
+      }
+#pragma unroll
+      for (int cp = 0; cp < C::CT / 2; ++cp) {
+        const int cw = co0 + wco * (BN / 2) + cp * 32 + kb * 4;   // native layout: tile 2cp rows kb*4.., +16: tile 2cp+1
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          csc[cp][t] = *reinterpret_cast<const f32x4*>(P.bn_scale + cw + 16 * t);
+          csh[cp][t] = *reinterpret_cast<const f32x4*>(P.bn_shift + cw + 16 * t);
+          cmu[cp][t] = *reinterpret_cast<const f32x4*>(P.bn_mean + cw + 16 * t);
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+#pragma unroll
+        for (int cp = 0; cp < C::CT / 2; ++cp) {
+          const u32x4 o = yraw[pt][cp];
+          const auto o0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+          const auto o1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+          const bf16x4 ya = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
+          const bf16x4 yb = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
+          bf16x4 ra, rb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float fa = (float)ya[j], fb = (float)yb[j];
+            const bool ona = fmaf(fa, csc[cp][0][j], csh[cp][0][j]) > 0.f;
+            const bool onb = fmaf(fb, csc[cp][1][j], csh[cp][1][j]) > 0.f;
+            ra[j] = (bf16_t)(ona ? acc[2 * cp][pt][j] : 0.f);
+            rb[j] = (bf16_t)(onb ? acc[2 * cp + 1][pt][j] : 0.f);
+            const float qa = (float)ra[j], qb = (float)rb[j];       // dz as stored (an OOB pixel loads y = 0 and is
+            bs[2 * cp][j] += qa;                                    //  dropped by its store: frames are 16-aligned here,
+            bq[2 * cp][j] = fmaf(qa, fa - cmu[cp][0][j], bq[2 * cp][j]);   // so that never happens)
+            bs[2 * cp + 1][j] += qb;
+            bq[2 * cp + 1][j] = fmaf(qb, fb - cmu[cp][1][j], bq[2 * cp + 1][j]);
+          }
+          const u32x2 ua = __builtin_bit_cast(u32x2, ra), ub = __builtin_bit_cast(u32x2, rb);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, drs[0], vo4[pt][cp], 0, 0);
+        }
+      }
+    } else {
     // v_permlane16_swap trades the (kb odd) rows of tile ct for the (kb even) rows of tile ct+1: afterwards lane kb
     // holds 8 CONSECUTIVE channels -- tile ct + (kb & 1), channels 8*(kb >> 1) .. +7 -- and writes 16 bytes (half
     // the store instructions, 64 contiguous bytes per pixel and tile pair).  Old values for the gradient fan-in
@@ -1190,6 +1262,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         }
       }
     }
+    }
     if (P.stats) {
 #pragma unroll
       for (int ct = 0; ct < C::CT; ++ct)
@@ -1242,6 +1315,8 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 
 __global__ __launch_bounds__(512, 1) void conv3_pdma128_kernel(const IgemmParams P) { conv3_pdma_body<128>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma64_kernel(const IgemmParams P) { conv3_pdma_body<64>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma128_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<128, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true>(P); }
 
 template <int BN>
 int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_parts) {
@@ -1250,16 +1325,21 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   P.nCo = P.Cout / BN;
   P.tilesX = cdiv(P.W, C::TW);
   P.tilesY = cdiv(P.H, C::TH);
-  auto kern = BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const bool bnbwd = P.bn_y != nullptr;
+  auto kern = bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
+                    : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel);
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[bnbwd]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
+    attr_done[bnbwd] = true;
   }
   const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);
   const long long stat_bytes = (long long)P.N * P.tilesY * P.tilesX * 2 * P.Cout * 4;
-  if (stat_bytes >= 0x7FFFFFFFLL) P.stats = nullptr;
+  if (stat_bytes >= 0x7FFFFFFFLL) {
+    UNET_REQUIRE(!bnbwd, UNET_ERR_UNSUPPORTED, "conv3_pdma: partial-sum buffer of %lld bytes", stat_bytes);
+    P.stats = nullptr;
+  }
   const int blocks = (int)std::min<long long>(256, cdiv64(work, 8) * 8);   // one per CU, a multiple of 8 (XCDs)
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   const long long n_tiles = (long long)P.N * P.tilesY * P.tilesX;
@@ -2079,6 +2159,56 @@ extern "C" int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32
   if (rc) return rc;
   if (parts == 0)   // this kernel variant has no fused statistics: one streaming pass over y instead
     rc = unet_internal_bn_partials(dtype, y, (int64_t)n * h * w, c_out, partial, &parts, s);
+  *n_parts = parts;
+  return rc;
+}
+
+// ---- data gradient of a 3x3 convolution fused with the ReLU mask and the BatchNorm-backward sums of the layer that
+// produced the convolution's input (the internal activation of DoubleConv, src/model.py:14-19)
+namespace {
+inline bool dgrad_bnrelu_pdma_ok(int dtype, int n, int h, int w, int c_in_gemm, int c_out_gemm) {
+  (void)n;
+  return dtype == UNET_BF16 && c_in_gemm >= 128 && c_in_gemm % 64 == 0 && c_out_gemm % 64 == 0 && h % 16 == 0 &&
+         w % 16 == 0 && (long long)h * w * c_out_gemm * 2 < 0x7FFFFFFFLL && (long long)h * w * c_in_gemm * 2 < 0x7FFFFFFFLL;
+}
+}  // namespace
+
+extern "C" int32_t unet_conv3x3_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_dy,
+                                                       int32_t c_dx) {
+  static const char* env = getenv("UNET_DGRAD_BN");       // tuning hook: "0" = never
+  if (env && env[0] == '0') return 0;
+  return dgrad_bnrelu_pdma_ok(dtype, n, h, w, c_dy, c_dx) ? 1 : 0;
+}
+
+extern "C" int32_t unet_conv3x3_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy, int32_t c_dy,
+                                             const void* w_packed, int32_t c_dx, const void* y_prev,
+                                             const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                             void* dz, float* partial, int32_t* n_parts, void* stream) {
+  UNET_REQUIRE(dy && w_packed && y_prev && bn_scale && bn_shift && bn_mean && dz && partial && n_parts, UNET_ERR_BAD_ARG,
+               "unet_conv3x3_dgrad_bnrelu: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_conv3x3_dgrad_bnrelu: bad dims");
+  UNET_REQUIRE(unet_conv3x3_dgrad_bnrelu_supported(dtype, n, h, w, c_dy, c_dx), UNET_ERR_UNSUPPORTED,
+               "unet_conv3x3_dgrad_bnrelu: %d -> %d channels at %dx%d (dtype %d) is not covered; use unet_conv3x3 + "
+               "unet_bn_relu_bwd", c_dy, c_dx, h, w, dtype);
+  IgemmParams P{};
+  P.src[0] = DView{(const char*)dy, c_dy, h, w, 0, 0};
+  P.src[1] = DView{nullptr, 0, 0, 0, 0, 0};
+  P.dst[0] = DViewW{(char*)dz, c_dx, h, w, 0, 0};
+  P.dst[1] = DViewW{nullptr, 0, 0, 0, 0, 0};
+  P.N = n; P.H = h; P.W = w;
+  P.Ctot = c_dy;
+  P.Cout = c_dx;
+  P.wK = c_dy;
+  P.w = (const char*)w_packed;
+  P.dst_split = c_dx;
+  P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
+  P.stats = partial;
+  P.bn_y = (const char*)y_prev;
+  P.bn_scale = bn_scale; P.bn_shift = bn_shift; P.bn_mean = bn_mean;
+  int parts = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int32_t rc = (c_dx % 128 == 0) ? launch_pdma<128>(P, UNET_K_CONV_DGRAD, s, &parts)
+                                       : launch_pdma<64>(P, UNET_K_CONV_DGRAD, s, &parts);
   *n_parts = parts;
   return rc;
 }

@@ -52,18 +52,30 @@ class _HipBlock(nn.Module):
         return _DTYPES[self.precision or _default_precision]
 
 
-def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, training: bool, first: bool = False):
+def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, first: bool = False, in_link=None, out_link=None,
+                  head=None):
+    """One conv3x3 -> BatchNorm2d -> ReLU third of DoubleConv.  Batch vs running statistics follow ``bn.training``
+    (the holder module itself, so a frozen ``bn.eval()`` inside a training model is honoured like in the reference's
+    nn.Sequential); ``bn.momentum is None`` is torch's cumulative moving average (factor 1 / num_batches_tracked).
+    ``head`` = (OutConv module, sigmoid): fuse the following 1x1 head (training path only)."""
+    training = bn.training
     track = training or bn.running_mean is None
-    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif training and bn.num_batches_tracked is not None:
+        momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)
+    else:
+        momentum = 0.0
     if first:
         ops._require_cuda(x)
         out = ops.FirstConvBnRelu.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                        track, momentum)
+                                        track, momentum, out_link)
     else:
         # inference (eval mode, no autograd recording): BatchNorm folded into the layer, one kernel
         fold = (not track) and not torch.is_grad_enabled()
+        hw, hb, hs = (head[0].conv.weight, head[0].conv.bias, head[1]) if head is not None else (None, None, False)
         out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   track, momentum, fold)
+                                   track, momentum, fold, in_link, out_link, hw, hb, hs)
     if training and bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -112,18 +124,27 @@ class DoubleConv(_HipBlock):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x, x_up=None):
+    def forward(self, x, x_up=None, head=None):
         """``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
-        tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly."""
+        tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly.
+        ``head`` (internal, optional): (OutConv, sigmoid) applied to the result -- in training mode the 1x1 head
+        is fused with the last BatchNorm + ReLU (the activation is never written)."""
         seq = self.double_conv
+        # the intermediate activation has exactly one consumer (the second convolution): its ReLU mask and
+        # BatchNorm-backward sums are produced by that convolution's data-gradient kernel (ops.BnLink)
+        link = ops.BnLink() if (seq[1].training and torch.is_grad_enabled()) else None
+        fuse_head = head is not None and ops.FUSE_BN_HEAD and seq[4].training
         if x_up is None and ops.first_layer_ok(x, seq[0], self.compute_dtype):
-            a = _conv_bn_relu(seq[0], seq[1], x, None, self.training, first=True)      # the image layer
-            return _conv_bn_relu(seq[3], seq[4], a, None, self.training)
-        x = ops.to_operator_layout(x, self.compute_dtype)
-        if x_up is not None:
-            x_up = ops.to_operator_layout(x_up, self.compute_dtype)
-        a = _conv_bn_relu(seq[0], seq[1], x, x_up, self.training)
-        return _conv_bn_relu(seq[3], seq[4], a, None, self.training)
+            a = _conv_bn_relu(seq[0], seq[1], x, None, first=True, out_link=link)      # the image layer
+        else:
+            x = ops.to_operator_layout(x, self.compute_dtype)
+            if x_up is not None:
+                x_up = ops.to_operator_layout(x_up, self.compute_dtype)
+            a = _conv_bn_relu(seq[0], seq[1], x, x_up, out_link=link)
+        out = _conv_bn_relu(seq[3], seq[4], a, None, in_link=link, head=head if fuse_head else None)
+        if head is not None and not fuse_head:
+            out = head[0](out, sigmoid=head[1])
+        return out
 
 
 class Down(_HipBlock):
@@ -153,7 +174,7 @@ class Up(_HipBlock):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels, out_channels, precision=precision)
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, head=None):
         dt = self.compute_dtype
         x1 = ops.to_operator_layout(x1, dt)
         x2 = ops.to_operator_layout(x2, dt)
@@ -161,7 +182,7 @@ class Up(_HipBlock):
             u = ops.Bilinear2x.apply(x1)
         else:
             u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
-        return self.conv(x2, u)
+        return self.conv(x2, u, head=head)
 
 
 class OutConv(_HipBlock):
@@ -241,7 +262,9 @@ class UNet(_HipBlock):
         self.up4 = Up(128, 64, bilinear, precision=precision)
         self.outc = OutConv(64, n_classes, precision=precision)
 
-    def forward(self, x):
+    def forward(self, x, sigmoid=False):
+        """``sigmoid`` (extra, optional): apply the sigmoid inside the head kernel (the seg-only trainer and
+        tester use probabilities, train.py / test.py); default = raw logits as the reference."""
         ops._require_cuda(x)
         _pack_cache(self)
         with _BatchedCounters():
@@ -249,8 +272,7 @@ class UNet(_HipBlock):
             y = self.up1(x5, x4)
             y = self.up2(y, x3)
             y = self.up3(y, x2)
-            y = self.up4(y, x1)
-            return self.outc(y)
+            return self.up4(y, x1, head=(self.outc, bool(sigmoid)))
 
 
 class SegmentationUNet(_HipBlock):
@@ -287,7 +309,7 @@ class SegmentationUNet(_HipBlock):
         noise.bernoulli_(1 - d.p).div_(1 - d.p)
         return ops.ChannelDropout.apply(x5, noise.view(x5.shape[0], x5.shape[1]))
 
-    def forward(self, x):
+    def forward(self, x, sigmoid=False):
         ops._require_cuda(x)
         _pack_cache(self)
         with _BatchedCounters():
@@ -296,8 +318,7 @@ class SegmentationUNet(_HipBlock):
             y = self.up1(x5, x4)
             y = self.up2(y, x3)
             y = self.up3(y, x2)
-            y = self.up4(y, x1)
-            return self.outc(y)
+            return self.up4(y, x1, head=(self.outc, bool(sigmoid)))
 
 
 class AnomalyUNet(_HipBlock):
@@ -326,8 +347,7 @@ class AnomalyUNet(_HipBlock):
         y = getattr(self, f"up1_{branch}")(x5, x4)
         y = getattr(self, f"up2_{branch}")(y, x3)
         y = getattr(self, f"up3_{branch}")(y, x2)
-        y = getattr(self, f"up4_{branch}")(y, x1)
-        return getattr(self, f"outc_{branch}")(y, sigmoid=True)
+        return getattr(self, f"up4_{branch}")(y, x1, head=(getattr(self, f"outc_{branch}"), True))
 
     two_streams = os.environ.get("UNET_TWO_STREAMS", "1") != "0"   # run the two independent decoders on two HIP streams (their kernels fill each
                            # other's ramp-up / tail; autograd replays each branch's backward on its own stream)

@@ -168,6 +168,7 @@ class PackCache:
         self.slots = {}        # (id(weight), mode) -> [packed view, rows, k, version]
         self.table = None
         self.ptrs = None
+        self.gen = -1          # ops._train_generation when the packs were last written
 
     def add(self, weight, mode, rows, k):
         if (id(weight), mode) not in self.slots:
@@ -195,19 +196,23 @@ class PackCache:
 
     def refresh(self, force=False):
         """``force``: repack regardless of the version counters (fused optimisers update parameters without
-        moving them, so a training forward always repacks: one ~0.1 ms launch)."""
+        moving them, so a training forward always repacks: one ~0.1 ms launch).  An eval-mode forward repacks when
+        any training forward happened since the last pack (``_train_generation`` moved): the optimiser step that
+        followed it changed the weights through raw pointers that no version counter sees."""
         if not self.items:
             return
         if self.table is None or self.ptrs != [w.data_ptr() for (w, _, _, _) in self.items]:
             self._build()
             stale = True
         else:
-            stale = force or any(self.slots[(id(w), m)][3] != w._version for (w, m, _, _) in self.items)
+            stale = force or self.gen != _train_generation or \
+                any(self.slots[(id(w), m)][3] != w._version for (w, m, _, _) in self.items)
         if stale:
             L.check(L.lib().unet_pack_weights_batched(_ptr(self.table), len(self.items), _DT[self.dtype], _stream()),
                     "unet_pack_weights_batched")
             for (w, m, _, _) in self.items:
                 self.slots[(id(w), m)][3] = w._version
+            self.gen = _train_generation
 
     def get(self, weight, mode, rows, k):
         s_ = self.slots.get((id(weight), mode))
@@ -324,13 +329,86 @@ def _folded_pack(weight, gamma, beta, running_mean, running_var, co, ctot, dtype
 
 
 # ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
+FUSE_BN_BWD = __import__("os").environ.get("UNET_FUSE_BN_BWD", "1") != "0"      # tuning hook (A/B runs)
+FUSE_BN_HEAD = __import__("os").environ.get("UNET_FUSE_BN_HEAD", "1") != "0"
+
+
+class BnLink:
+    """Side channel between a conv-BN-ReLU layer and the ONE operator that consumes its activation (the second
+    convolution of the same DoubleConv, /root/reference/src/model.py:14-19).  In the backward pass the consumer's data
+    gradient kernel applies this layer's ReLU mask in its epilogue and leaves the BatchNorm-backward partial sums
+    (sum dz, sum dz*(y - mean)) here, so the producer skips its reduction pass over (y, da).  Only valid for an
+    activation with exactly one consumer -- the model code creates links for DoubleConv's internal tensor only."""
+
+    __slots__ = ("y", "coef", "partial", "n_parts", "dz_ptr")
+
+    def __init__(self):
+        self.y = None          # raw conv output of the producer (NHWC compute dtype)
+        self.coef = None       # [4, C]: mean, istd, scale, shift
+        self.partial = None
+        self.n_parts = 0
+        self.dz_ptr = 0        # data_ptr of the premasked gradient the consumer returned (0: not premasked)
+
+
+def _bn_stats_conv(lib, dt, n, h, w, src, wp, co, y, gamma, beta, running_mean, running_var, momentum, coef, dev, st):
+    """conv + BatchNorm batch statistics in one call (the conv epilogue reduces sum / sum of squares per channel
+    with wavefront shuffles, or one extra streaming pass for kernels without that epilogue) + fp64 finalize."""
+    cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+    part = _workspace(cap * 2 * co * 4, dev)
+    nparts = C.c_int32(0)
+    L.check(lib.unet_conv3x3_stats(dt, n, h, w, src, _ptr(wp), co, _ptr(y), _ptr(part), C.byref(nparts), st),
+            "unet_conv3x3_stats")
+    L.check(lib.unet_bn_finalize_partials(_ptr(part), nparts.value, n * h * w, co, _ptr(gamma), _ptr(beta),
+                                          _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
+                                          _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
+            "unet_bn_finalize_partials")
+
+
+def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, st):
+    """Gradient w.r.t. the raw conv output of a conv-BN-ReLU layer -> (dy, dgamma/dbeta [2, C]).  Premasked path: the
+    consumer's data-gradient kernel already applied the ReLU mask and reduced the BatchNorm-backward sums (BnLink)."""
+    n, co, h, w = y.shape
+    pixels = n * h * w
+    dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
+    if link is not None and link.dz_ptr and link.dz_ptr == da.data_ptr() and da.dtype == dtype and _is_nhwc(da):
+        dy = da
+        ws = _workspace(3 * co * 4, dev)
+        L.check(lib.unet_bn_bwd_premasked(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]),
+                                          _ptr(coef[1]), _ptr(link.partial), link.n_parts, _ptr(dgb[0]),
+                                          _ptr(dgb[1]), _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
+    else:
+        if link is not None and link.dz_ptr:
+            raise RuntimeError("conv-BN-ReLU: the premasked gradient of a linked activation did not arrive unchanged "
+                               "(the activation has a second consumer?)")
+        if out_sink is not None:
+            out_sink.collect(da, dev)
+        da = _as_nhwc(da, dtype)
+        dy = _nhwc_empty(n, co, h, w, dtype, dev)
+        ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
+        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
+                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
+                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+    if link is not None:
+        link.y = link.coef = link.partial = None
+        link.dz_ptr = 0
+    return dy, dgb
+
+
 class ConvBnRelu(torch.autograd.Function):
     """relu(batch_norm(conv3x3(cat([x0, x1])))) -- one third of DoubleConv
     (/root/reference/src/model.py:14-16 / :17-19); ``x1`` (optional) is the up-sampled tensor
-    of Up.forward, centre-padded to x0's size (src/model.py:57-65) without materialising pad or cat."""
+    of Up.forward, centre-padded to x0's size (src/model.py:57-65) without materialising pad or cat.
+
+    Optional fusions of the training path (all value-preserving):
+      * ``head_w`` / ``head_b`` / ``head_sigmoid``: the layer is followed by OutConv (src/model.py:72): the 1x1 head
+        reads the RAW conv output and applies BatchNorm + ReLU on load, its backward writes the ReLU-masked gradient
+        and the BatchNorm-backward sums -- no activation tensor, no BN-apply pass, no (y, da) reduction pass.
+        The function then returns the head's NCHW fp32 output.
+      * ``out_link`` / ``in_link`` (BnLink): see BnLink."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum, fold=False):
+    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum, fold=False,
+                in_link=None, out_link=None, head_w=None, head_b=None, head_sigmoid=False):
         _require_cuda(x0, weight)
         dtype = x0.dtype
         dt = _DT[dtype]
@@ -346,6 +424,8 @@ class ConvBnRelu(torch.autograd.Function):
         ctot = c0 + c1
         if not (ci <= ctot < ci + 64):
             raise ValueError(f"conv weight expects {ci} input channels, activations carry {ctot}")
+        if head_w is not None and not training:
+            raise RuntimeError("ConvBnRelu: the fused head is a training-path fusion")
         lib, st, dev = L.lib(), _stream(), x0.device
         y = _nhwc_empty(n, co, h, w, dtype, dev)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
@@ -357,17 +437,8 @@ class ConvBnRelu(torch.autograd.Function):
         if training:
             global _train_generation
             _train_generation += 1
-            # conv + BatchNorm batch statistics in one call: the conv epilogue reduces sum / sum-of-squares per
-            # channel with wavefront shuffles (or one extra streaming pass for kernels without that epilogue)
-            cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
-            part = _workspace(cap * 2 * co * 4, dev)
-            nparts = C.c_int32(0)
-            L.check(lib.unet_conv3x3_stats(dt, n, h, w, src, _ptr(wp), co, _ptr(y), _ptr(part), C.byref(nparts), st),
-                    "unet_conv3x3_stats")
-            L.check(lib.unet_bn_finalize_partials(_ptr(part), nparts.value, pixels, co, _ptr(gamma), _ptr(beta),
-                                                  _ptr(running_mean), _ptr(running_var), momentum, BN_EPS,
-                                                  _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
-                    "unet_bn_finalize_partials")
+            _bn_stats_conv(lib, dt, n, h, w, src, wp, co, y, gamma, beta, running_mean, running_var, momentum, coef,
+                           dev, st)
         elif fold:
             # inference: BatchNorm(eval) folded into the layer -- scale into the packed weights, shift + ReLU in the
             # convolution's epilogue: one kernel, the activation is written once
@@ -380,18 +451,33 @@ class ConvBnRelu(torch.autograd.Function):
             L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
             L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                             BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
+        ctx.geom = (oy, ox, training)
+        ctx.sink0 = getattr(x0, "_unet_sink", None)     # x0 is a skip with a shared gradient buffer
+        ctx.out_sink = None                              # set by share_grad() when THIS output is a skip
+        ctx.in_link = in_link if (in_link is not None and in_link.y is not None and x1 is None) else None
+        ctx.out_link = None
+        ctx.head = None
+        if head_w is not None:
+            hc = head_w.shape[0]
+            out = torch.empty((n, hc, h, w), dtype=torch.float32, device=dev)
+            L.check(lib.unet_head_bnrelu_fwd(dt, _ptr(y), n, h, w, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(head_w),
+                                             _ptr(head_b), hc, int(head_sigmoid), _ptr(out), st), "unet_head_bnrelu_fwd")
+            ctx.save_for_backward(x0, x1, y, weight, gamma, coef, head_w, out)
+            ctx.head = bool(head_sigmoid)
+            return out
         a = _nhwc_empty(n, co, h, w, dtype, dev)
         L.check(lib.unet_bn_relu_apply(dt, _ptr(y), pixels, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(a), st),
                 "unet_bn_relu_apply")
         ctx.save_for_backward(x0, x1, y, weight, gamma, coef)
-        ctx.geom = (oy, ox, training)
-        ctx.sink0 = getattr(x0, "_unet_sink", None)     # x0 is a skip with a shared gradient buffer
-        ctx.out_sink = None                              # set by share_grad() when THIS output is a skip
+        if out_link is not None and training:
+            out_link.y, out_link.coef, out_link.dz_ptr = y, coef, 0
+            ctx.out_link = out_link
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x0, x1, y, weight, gamma, coef = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x0, x1, y, weight, gamma, coef = saved[:6]
         oy, ox, training = ctx.geom
         if not training:
             raise RuntimeError("backward through BatchNorm in eval mode is not on the hot path (unsupported)")
@@ -401,16 +487,31 @@ class ConvBnRelu(torch.autograd.Function):
         co, ci = weight.shape[0], weight.shape[1]
         ctot = c0 + (0 if x1 is None else x1.shape[1])
         lib, st, dev = L.lib(), _stream(), x0.device
-        if ctx.out_sink is not None:
-            ctx.out_sink.collect(da, dev)
-        da = _as_nhwc(da, dtype)
         pixels = n * h * w
-        dy = _nhwc_empty(n, co, h, w, dtype, dev)
         dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
-        ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
-        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
-                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
-                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+        dhw = dhb = None
+        link = ctx.out_link
+        if ctx.head is not None:
+            # OutConv backward + ReLU mask + BatchNorm-backward sums in one pass, then dy = A*dz + B*y + K in place
+            head_w, out = saved[6], saved[7]
+            hc = head_w.shape[0]
+            dout = da.contiguous().float()
+            dy = _nhwc_empty(n, co, h, w, dtype, dev)
+            dhw = torch.empty_like(head_w, dtype=torch.float32)
+            dhb = torch.empty(hc, dtype=torch.float32, device=dev)
+            part = torch.empty((lib.unet_head_bnrelu_max_parts(), 2, co), dtype=torch.float32, device=dev)
+            nparts = C.c_int32(0)
+            ws = _workspace(lib.unet_head_bwd_workspace(n, h, w, co, hc), dev)
+            L.check(lib.unet_head_bnrelu_bwd(dt, _ptr(y), _ptr(coef[2]), _ptr(coef[3]), _ptr(coef[0]), _ptr(out),
+                                             _ptr(dout), n, h, w, co, _ptr(head_w), hc, int(ctx.head), _ptr(dy),
+                                             _ptr(dhw), _ptr(dhb), _ptr(part), C.byref(nparts), _ptr(ws), ws.numel(),
+                                             st), "unet_head_bnrelu_bwd")
+            ws = _workspace(3 * co * 4, dev)
+            L.check(lib.unet_bn_bwd_premasked(dt, _ptr(dy), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]),
+                                              _ptr(coef[1]), _ptr(part), nparts.value, _ptr(dgb[0]), _ptr(dgb[1]),
+                                              _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
+        else:
+            dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, ctx.out_sink, dev, st)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         dw = None
         wgrad_done = None
@@ -440,21 +541,35 @@ class ConvBnRelu(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             wp = packed(weight, L.PACK_CONV_DGRAD, ctot, co, dtype)
             sink = ctx.sink0
-            fan_in = sink is not None and sink.begin(dev)
-            dx0 = sink.buf if fan_in else _nhwc_empty(n, c0, h, w, dtype, dev)
-            if x1 is not None:
-                dx1 = _nhwc_empty(*x1.shape, dtype, dev)
-            dsrc = _views([(dy, 0, 0), None])
-            ddst = _views([(dx0, 0, 0), None if x1 is None else (dx1, oy, ox)])
-            L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 1 if fan_in else 0,
-                                     L.K_CONV_DGRAD, st), "unet_conv3x3(dgrad)")
-            if sink is not None:
-                sink.done(dx0, dev)
-                if fan_in:
-                    dx0 = None              # already inside the buffer the first consumer returned
+            ilink = ctx.in_link if (FUSE_BN_BWD and sink is None and x1 is None) else None
+            if ilink is not None and ilink.y is not None and \
+                    lib.unet_conv3x3_dgrad_bnrelu_supported(dt, n, h, w, co, c0):
+                # data gradient + ReLU mask of the PRODUCER of x0 + its BatchNorm-backward sums in one kernel
+                dx0 = _nhwc_empty(n, c0, h, w, dtype, dev)
+                cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+                part = torch.empty((cap, 2, c0), dtype=torch.float32, device=dev)
+                nparts = C.c_int32(0)
+                pc = ilink.coef
+                L.check(lib.unet_conv3x3_dgrad_bnrelu(dt, n, h, w, _ptr(dy), co, _ptr(wp), c0, _ptr(ilink.y),
+                                                      _ptr(pc[2]), _ptr(pc[3]), _ptr(pc[0]), _ptr(dx0), _ptr(part),
+                                                      C.byref(nparts), st), "unet_conv3x3_dgrad_bnrelu")
+                ilink.partial, ilink.n_parts, ilink.dz_ptr = part, nparts.value, dx0.data_ptr()
+            else:
+                fan_in = sink is not None and sink.begin(dev)
+                dx0 = sink.buf if fan_in else _nhwc_empty(n, c0, h, w, dtype, dev)
+                if x1 is not None:
+                    dx1 = _nhwc_empty(*x1.shape, dtype, dev)
+                dsrc = _views([(dy, 0, 0), None])
+                ddst = _views([(dx0, 0, 0), None if x1 is None else (dx1, oy, ox)])
+                L.check(lib.unet_conv3x3(dt, n, h, w, dsrc, _ptr(wp), ctot, ddst, c0, 1 if fan_in else 0,
+                                         L.K_CONV_DGRAD, st), "unet_conv3x3(dgrad)")
+                if sink is not None:
+                    sink.done(dx0, dev)
+                    if fan_in:
+                        dx0 = None              # already inside the buffer the first consumer returned
         if wgrad_done is not None:
             torch.cuda.current_stream(dev).wait_event(wgrad_done)
-        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None, None
+        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, dhw, dhb, None
 
 
 class FirstConvBnRelu(torch.autograd.Function):
@@ -463,7 +578,7 @@ class FirstConvBnRelu(torch.autograd.Function):
     the reduction is one MFMA step (unet_conv3x3_first_*), no 64-channel padded copy of the image exists."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, out_link=None):
         _require_cuda(x, weight)
         x = x.contiguous().float()
         n, ci, h, w = x.shape
@@ -495,6 +610,10 @@ class FirstConvBnRelu(torch.autograd.Function):
         ctx.save_for_backward(x, y, weight, gamma, coef)
         ctx.training = training
         ctx.out_sink = None
+        ctx.out_link = None
+        if out_link is not None and training:
+            out_link.y, out_link.coef, out_link.dz_ptr = y, coef, 0
+            ctx.out_link = out_link
         return a
 
     @staticmethod
@@ -507,16 +626,7 @@ class FirstConvBnRelu(torch.autograd.Function):
         n, ci, h, w = x.shape
         co = weight.shape[0]
         lib, st, dev = L.lib(), _stream(), x.device
-        if ctx.out_sink is not None:
-            ctx.out_sink.collect(da, dev)
-        da = _as_nhwc(da, dtype)
-        pixels = n * h * w
-        dy = _nhwc_empty(n, co, h, w, dtype, dev)
-        dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
-        ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
-        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
-                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
-                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+        dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, ctx.out_link, ctx.out_sink, dev, st)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=torch.float32)
@@ -524,7 +634,7 @@ class FirstConvBnRelu(torch.autograd.Function):
             ws2 = _workspace(need, dev)
             L.check(lib.unet_conv3x3_first_wgrad(n, h, w, _ptr(x), ci, _ptr(dy), _ptr(dw), _ptr(ws2), ws2.numel(), st),
                     "unet_conv3x3_first_wgrad")
-        return None, dw, dgb[0], dgb[1], None, None, None, None
+        return None, dw, dgb[0], dgb[1], None, None, None, None, None
 
 
 FIRST_LAYER_KERNELS = __import__("os").environ.get("UNET_FIRST_LAYER", "1") != "0"
