@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")   # (override: diagnostic builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 UNET_F32, UNET_BF16 = 0, 1

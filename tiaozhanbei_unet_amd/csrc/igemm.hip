@@ -1075,6 +1075,10 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   dma_w(d_wbase, 0, 0, 0, true);
   dma_w(d_wbase, 0, 1, 1, true);
 
+#ifdef PDMA_STAMPS
+  // diagnostic build: per-wave cycle sums of (vmcnt wait, barrier, DMA issue, fragment reads + MFMAs) over all taps
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0, st_taps = 0, st_epi = 0;
+#endif
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
   bool after_epilogue = false;
   float stat_tot = 0.f;                           // block-mode BatchNorm partial of this thread's (statistic, channel)
@@ -1102,6 +1106,10 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       const int pbuf = pbuf_i * C::A_BYTES;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
+#ifdef PDMA_STAMPS
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+        if (st_prev) st_sum[3] += st_a - st_prev;
+#endif
         // W(step) was issued two steps ago; younger: the previous step's [patch DMA] + NDW weight DMAs
         // [+ the NST (+1) output stores of the previous work item's epilogue]
         if (tap == 0 && c == 0 && after_epilogue) {
@@ -1112,16 +1120,32 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         } else {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + 1) : "memory");
         }
+#ifdef PDMA_STAMPS
+        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+        st_sum[0] += st_b - st_a;
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef PDMA_STAMPS
+        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+        st_sum[1] += st_c - st_b;
+#endif
         if (tap < C::NDA) dma_patch(last ? 0 : c + 1, tap, pbuf_i ^ 1, last ? d_live : true);
         if (tap + 2 < 9) dma_w(c_wbase, c, tap + 2, (tap + 2) % 3, true);
         else if (!last) dma_w(c_wbase, c + 1, tap + 2 - 9, (tap + 2) % 3, true);
         else dma_w(d_wbase, 0, tap + 2 - 9, (tap + 2) % 3, d_live);
+#ifdef PDMA_STAMPS
+        st_prev = __builtin_amdgcn_s_memtime();
+        st_sum[2] += st_prev - st_c;
+        st_taps += 1;
+#endif
         compute(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
       }
       pbuf_i ^= 1;
     }
 
+#ifdef PDMA_STAMPS
+    { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_sum[3] += t - st_prev; st_prev = 0; st_epi -= t; }
+#endif
     // ---- epilogue: D of 16x16x32: col = lane&15 (pixel), rows (lane>>4)*4 + reg (4 consecutive channels).
     // Buffer stores (out-of-range offset = dropped) so every lane issues exactly NST of them.
     __amdgpu_buffer_rsrc_t drs[2];
@@ -1309,7 +1333,16 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tsum), srs, so, 0, 0);
     }
     after_epilogue = true;
+#ifdef PDMA_STAMPS
+    st_epi += __builtin_amdgcn_s_memtime();
+#endif
   }
+#ifdef PDMA_STAMPS
+  if (P.bn_mean && lane == 0) {
+    unsigned long long* o = (unsigned long long*)P.bn_mean + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = st_sum[0]; o[1] = st_sum[1]; o[2] = st_sum[2]; o[3] = st_sum[3]; o[4] = st_taps; o[5] = st_epi;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy DMAs before the wave ends
 }
 
@@ -1317,6 +1350,10 @@ __global__ __launch_bounds__(512, 1) void conv3_pdma128_kernel(const IgemmParams
 __global__ __launch_bounds__(512, 1) void conv3_pdma64_kernel(const IgemmParams P) { conv3_pdma_body<64>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma128_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<128, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true>(P); }
+
+#ifdef PDMA_STAMPS
+void* g_pdma_debug = nullptr;
+#endif
 
 template <int BN>
 int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_parts) {
@@ -1345,6 +1382,9 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   const long long n_tiles = (long long)P.N * P.tilesY * P.tilesX;
   P.zdiv = (P.stats && n_tiles % blocks == 0) ? 1 : 0;       // block-mode statistics: every block visits every channel tile
   if (P.stats && stat_parts) *stat_parts = P.zdiv ? blocks : (int)n_tiles;
+#ifdef PDMA_STAMPS
+  if (!bnbwd) P.bn_mean = (const float*)g_pdma_debug;
+#endif
   ProfScope prof(kclass, flops, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("conv3_pdma_kernel");
@@ -2275,3 +2315,7 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
   unet_set_error("unet_convt2x2_dgrad: dtype %d", dtype);
   return UNET_ERR_BAD_ARG;
 }
+
+#ifdef PDMA_STAMPS
+extern "C" void unet_debug_set_buffer(void* p) { g_pdma_debug = p; }
+#endif
