@@ -7,9 +7,18 @@
 
 One "step" = forward + CombinedLoss (MSE + focal) + backward + (RCCL gradient all-reduce when N>1) +
 Adam, on synthetic 3x256x256 batches already resident in HBM (BASELINE.json configs[2], synthetic data).
+Other single-GPU legs: `--ssim` (configs[2] as written: SSIM reconstruction head + focal) and
+`--model unet --precision fp32 --batch 16` (configs[1]: UNet(3,1) seg-only, focal on sigmoid(logits)).
+
+Timing: W warm-up steps, then `--blocks` (default 5) timed blocks of EXACTLY K steps, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  `value` / `ms_per_step` are those of the
+MEDIAN block (boxes of the pool differ by up to 10 %, blocks on one box by ~1 %); `ms_per_step_p10/p90/blocks` say so.
+
 Prints ONE JSON line (rank 0) with the driver's contract plus:
-  roofline     -- the dominant kernel class, timed live with hipEvents on its own stream
-                  (libunet_hip's per-class event brackets) against the dense MFMA peak of the dtype;
+  roofline     -- the dominant KERNEL (most event time among the MFMA kernels), timed live with hipEvents on its own
+                  stream (libunet_hip's per-launch brackets) against the dense MFMA peak of the dtype; `traffic` =
+                  HBM bytes per launch of that kernel from the committed PMC passes of this same command
+                  (profiles/r02_pmc_traffic.json, tools/pmc_traffic.sh), beside its algorithmic bytes;
   cpu_baseline -- the CPU oracle (a port of the reference's train step) timed on this box's host cores
                   on a bounded sample (N=1 only).
 """
@@ -24,8 +33,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FWD_GFLOP_PER_IMG_256 = 158.637      # AnomalyUNet forward, 256x256
+FWD_GFLOP_PER_IMG_256 = {"anomaly_unet": 158.637, "unet": 96.335}      # SURVEY 8(d), forward, 256x256
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -33,13 +43,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (median reported)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 32 (unet: 16)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="anomaly_unet", choices=["anomaly_unet", "unet"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"], help="default bf16 (unet: fp32, configs[1])")
+    ap.add_argument("--ssim", action="store_true", help="SSIM reconstruction head instead of MSE (configs[2] --use_ssim)")
     ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "zeros"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--no-roofline", action="store_true", help="skip the two event-bracketed extra steps (PMC passes)")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.model == "anomaly_unet" else 16
+    if args.precision is None:
+        args.precision = "bf16" if args.model == "anomaly_unet" else "fp32"
+    return args
 
 
 def host_cores():
@@ -59,26 +78,40 @@ def host_cores():
     return n if n <= 32 else 16
 
 
-def cpu_baseline(size, batch):
-    """The oracle's train step (fwd + MSE/focal + bwd + Adam) on the host cores, bounded sample."""
+def cpu_baseline(size, batch, model):
+    """The oracle's train step (fwd + loss + bwd + Adam) on the host cores, bounded sample (~10-20 s)."""
     from oracle import unet_oracle as O, weights as W
     cores = host_cores()
     torch.set_num_threads(cores)
-    state = dict(W.make_state(W.state_spec("anomaly_unet", 3, 1, False), 0))
+    kind = "anomaly_unet" if model == "anomaly_unet" else "unet"
+    state = dict(W.make_state(W.state_spec(kind, 3, 1, False), 0))
     g = torch.Generator().manual_seed(42)
     image = torch.randn(batch, 3, size, size, generator=g)
     mask = (torch.rand(batch, 1, size, size, generator=g) < 0.02).float()
     opt = {}
-    state, _ = O.train_step(state, opt, image, mask)          # warm-up (allocations, oneDNN primitives)
+    kw = dict(model=kind) if kind == "anomaly_unet" else dict(model="unet", recon_weight=0.0)
+    state, _ = O.train_step(state, opt, image, mask, **kw)          # warm-up (allocations, oneDNN primitives)
     t0 = time.perf_counter()
     steps = 0
-    while steps < 8 and (steps < 2 or time.perf_counter() - t0 < 10.0):     # ~10 s of host work, at least 2 steps
-        state, _ = O.train_step(state, opt, image, mask)
+    while steps < 6 and (steps < 2 or time.perf_counter() - t0 < 12.0):     # ~12 s of host work, at least 2 steps
+        state, _ = O.train_step(state, opt, image, mask, **kw)
         steps += 1
     dt = time.perf_counter() - t0
+    name = "AnomalyUNet" if kind == "anomaly_unet" else "UNet(3,1) seg-only"
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed steps ({dt:.1f} s, after 1 warm-up) of the oracle train step, AnomalyUNet "
+            "sample": f"{steps} timed steps ({dt:.1f} s, after 1 warm-up) of the oracle train step, {name} "
                       f"{size}x{size} bs={batch} fp32, torch {torch.__version__} CPU"}
+
+
+def layer_bytes(model, n, s, es):
+    """Algorithmic bytes (input + weights + output, each once) of the 3x3 convolutions of one forward, per layer:
+    [(cin, cout, hw, bytes)].  Used for the algorithmic-bytes figure beside roofline.traffic."""
+    enc = [(3, 64, s), (64, 64, s), (64, 128, s // 2), (128, 128, s // 2), (128, 256, s // 4), (256, 256, s // 4),
+           (256, 512, s // 8), (512, 512, s // 8), (512, 1024, s // 16), (1024, 1024, s // 16)]
+    dec = [(1024, 512, s // 8), (512, 512, s // 8), (512, 256, s // 4), (256, 256, s // 4), (256, 128, s // 2),
+           (128, 128, s // 2), (128, 64, s), (64, 64, s)]
+    layers = enc + dec * (2 if model == "anomaly_unet" else 1)
+    return [(ci, co, hw, n * hw * hw * (max(ci, 64) + co) * es + 9 * ci * co * es) for ci, co, hw in layers]
 
 
 def main():
@@ -104,11 +137,18 @@ def main():
     from tiaozhanbei_unet_amd.ddp import DataParallel
 
     torch.manual_seed(0)                                    # identical init on every rank
-    model = P.AnomalyUNet(3, precision=args.precision).to(dev)
+    if args.model == "anomaly_unet":
+        core = P.AnomalyUNet(3, precision=args.precision).to(dev)
+        model = core
+        criterion = P.CombinedLoss(recon_criterion=P.SSIMLoss() if args.ssim else None)
+    else:
+        from tiaozhanbei_unet_amd.train import _SegOnly
+        core = P.UNet(3, 1, precision=args.precision).to(dev)
+        model = _SegOnly(core)                             # (input as dummy reconstruction, sigmoid(logits))
+        criterion = P.CombinedLoss(recon_weight=0.0, seg_weight=1.0)
     model.train()
     net = DataParallel(model) if world > 1 else model
-    criterion = P.CombinedLoss()
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    optimizer = P.get_optimizer(core, "adam", 1e-3, 1e-4)
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
     n, s = args.batch, args.size
@@ -136,46 +176,74 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    loss_val = float(losses["total_loss"])
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            losses = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        block_s.append(elapsed)
+    loss_val = float(losses["total_loss"].detach())
+    ordered = sorted(block_s)
+    elapsed = ordered[len(ordered) // 2] if len(ordered) % 2 else 0.5 * (ordered[len(ordered) // 2 - 1] + ordered[len(ordered) // 2])
 
-    # ---- roofline of the dominant kernel class: hipEvent brackets inside libunet_hip, 2 extra steps
+    def pct(q):
+        return ordered[min(len(ordered) - 1, max(0, int(round(q * (len(ordered) - 1)))))]
+
+    # ---- roofline of the dominant kernel: hipEvent brackets inside libunet_hip, 2 extra steps
     roof = None
-    # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
-    # The two decoder branches normally run on two HIP streams; for these two steps they run on ONE stream so
-    # that an event bracket times its kernel alone (concurrent kernels would inflate each other's brackets).
-    model.two_streams = False
-    if rank == 0:
-        ops.prof_enable(True)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    if rank == 0:
-        prof = ops.prof_collect()
-        ops.prof_enable(False)
-        mfma = {k: v for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
-        if mfma:
-            name = max(mfma, key=lambda k: mfma[k]["ms"])
-            d = mfma[name]
-            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            peak = PEAK[args.precision]
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                    "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
-                    "measured": "hipEvent brackets on the launch stream, 2 single-stream steps after the timed region",
-                    "per_class_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in prof.items() if v["launches"]},
-                    "per_class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
-                                         for k, v in mfma.items()}}
+    if not args.no_roofline:
+        # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
+        # The two decoder branches normally run on two HIP streams; for these two steps they run on ONE stream so
+        # that an event bracket times its kernel alone (concurrent kernels would inflate each other's brackets).
+        if hasattr(core, "two_streams"):
+            core.two_streams = False
+        if rank == 0:
+            ops.prof_enable(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            prof = ops.prof_collect()
+            kern = ops.prof_kernels()
+            ops.prof_enable(False)
+            mfma = {k: v for k, v in kern.items() if v["flops"] > 0 and v["ms"] > 0}
+            if mfma:
+                name = max(mfma, key=lambda k: mfma[k]["ms"])
+                d = mfma[name]
+                achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                peak = PEAK[args.precision]
+                es = 2 if args.precision == "bf16" else 4
+                traffic, traffic_note = None, "no PMC summary for this kernel in profiles/r02_pmc_traffic.json"
+                try:
+                    pmc = json.load(open(PMC_FILE))["kernels"]
+                    key = name.split(" ")[0]
+                    if key in pmc:
+                        traffic = pmc[key]["traffic_bytes_per_launch"]
+                        traffic_note = ("bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from the rocprofv3 --pmc passes of "
+                                        "this command (profiles/r02_pmc_traffic.json; default config only)")
+                except (OSError, ValueError, KeyError):
+                    pass
+                # algorithmic bytes of the layers that kernel serves (>= 128 input channels, forward + data gradient)
+                lb = [b for (ci, co, hw, b) in layer_bytes(args.model, n, s, es) if ci >= 128]
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_note": traffic_note,
+                        "algorithmic_bytes_per_launch": int(sum(lb) / max(len(lb), 1)) if "pdma" in name else None,
+                        "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
+                        "measured": "hipEvent brackets on the launch stream, 2 single-stream steps after the timed region",
+                        "per_kernel_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
+                        "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in mfma.items()},
+                        "per_class_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in prof.items() if v["launches"]},
+                        "per_class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
+                                             for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}}
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -184,23 +252,35 @@ def main():
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
         scale = (s * s) / 65536.0
-        train_tflops = 3 * FWD_GFLOP_PER_IMG_256 * scale * value / 1e3
+        train_tflops = 3 * FWD_GFLOP_PER_IMG_256[args.model] * scale * value / 1e3
+        if args.model == "anomaly_unet":
+            metric = f"training images/sec, AnomalyUNet {s}x{s} bs={args.batch} per GPU"
+            loss_name = "SSIM+focal loss (--use_ssim)" if args.ssim else "MSE+focal loss"
+            workload = (f"AnomalyUNet 3x{s}x{s}, bs={args.batch}/GPU, {loss_name}, Adam (BASELINE.json configs[2], "
+                        f"synthetic randn images, {args.mask} masks)")
+        else:
+            metric = f"training images/sec, UNet(3,1) {s}x{s} bs={args.batch} per GPU (seg-only)"
+            workload = (f"UNet(3,1) 3x{s}x{s}, bs={args.batch}/GPU, focal loss on sigmoid(logits), Adam (BASELINE.json "
+                        f"configs[1], synthetic randn images, {args.mask} masks)")
         out = {
-            "metric": "training images/sec, AnomalyUNet 256x256 bs=32 per GPU", "value": round(value, 2),
+            "metric": metric, "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"AnomalyUNet 3x{s}x{s}, bs={args.batch}/GPU, MSE+focal loss, Adam "
-                                   f"(BASELINE.json configs[2], synthetic randn images, {args.mask} masks)",
+            "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "accumulate": "fp32", "master_params": "fp32"},
+            "blocks": len(block_s),
+            "ms_per_step_blocks": [round(1e3 * b / args.steps, 3) for b in block_s],
+            "ms_per_step_p10": round(1e3 * pct(0.1) / args.steps, 3),
+            "ms_per_step_p90": round(1e3 * pct(0.9) / args.steps, 3),
             "model_tflops": round(train_tflops, 1),
             "mfma_frac_of_peak_whole_step": round(train_tflops / PEAK[args.precision] / world, 4),
             "final_loss": round(loss_val, 5),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(s, args.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(s, args.cpu_batch, args.model)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

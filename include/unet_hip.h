@@ -66,6 +66,9 @@ int32_t unet_prof_enable(int32_t on);
 /* Synchronises the recorded events; fills ms[UNET_K_COUNT], launches[UNET_K_COUNT],
  * flops[UNET_K_COUNT] (algorithmic FLOPs summed over the launches) and clears the log. */
 int32_t unet_prof_collect(double* ms, int64_t* launches, double* flops);
+/* Per-KERNEL breakdown of the brackets consumed by the last unet_prof_collect(): entry `index` (0, 1, ... until
+ * UNET_ERR_BAD_ARG) -> kernel name (static string), summed event time, launches, algorithmic FLOPs. */
+int32_t unet_prof_kernel_stats(int32_t index, const char** name, double* ms, int64_t* launches, double* flops);
 
 /* ---- layout ------------------------------------------------------------------------- */
 /* NCHW fp32 -> NHWC compute dtype with the channel dim zero-padded to c_pad
@@ -195,6 +198,10 @@ int32_t unet_bn_finalize_partials(const float* partial, int32_t n_parts, int64_t
 /* eval: scale/shift from the running statistics. */
 int32_t unet_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* eval coefficients plus the constants the FROZEN backward needs: mean = running_mean, istd = 1/sqrt(running_var+eps). */
+int32_t unet_bn_eval_coeffs4(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, float* mean, float* istd, float* scale,
+                             float* shift, void* stream);
 /* a = max(fma(y, scale, shift), 0) */
 int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixels, int32_t c, const float* scale,
                            const float* shift, void* a, void* stream);
@@ -205,6 +212,13 @@ int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t p
                          const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* backward of a = relu(bn(y)) with FROZEN statistics (a BatchNorm2d put in eval() inside a training model -- the
+ * fine-tuning pattern the reference's nn.Sequential honours, src/model.py:13-20): mean / istd are constants, so
+ * dy = gamma*istd*dz; dgamma = sum dz*yhat, dbeta = sum dz as usual.  Same workspace as unet_bn_relu_bwd. */
+int32_t unet_bn_relu_bwd_frozen(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                                const float* gamma, const float* mean, const float* istd, const float* scale,
+                                const float* shift, float* dgamma, float* dbeta, void* dy, void* workspace,
+                                size_t workspace_bytes, void* stream);
 /* The same backward when the producer of the gradient has already applied the ReLU mask in its own epilogue and left
  * the two per-channel sums behind (unet_head_bnrelu_bwd, unet_conv3x3_dgrad_bnrelu): dz = da*[z>0] (compute dtype,
  * NHWC), partial = fp32 [n_parts][2][c] holding sum dz and sum dz*(y - mean).  Ordered fp64 finalize -> dgamma, dbeta,
@@ -270,6 +284,12 @@ size_t unet_ssim_workspace(int32_t planes, int32_t h, int32_t w);
 int32_t unet_ssim_loss(const float* img1, const float* img2, int32_t planes, int32_t h, int32_t w,
                        int32_t window, float* loss, float* d_img1, float* d_img2, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* SSIMLoss(size_average=False) (train_utils.py:84-87): loss[i] = 1 - mean_{c,h,w} ssim_map of image i (n images of c
+ * planes); d_img1 / d_img2 (may be NULL) receive d loss[i] / d img for image i.  workspace: unet_ssim_workspace(c, h, w). */
+int32_t unet_ssim_loss_per_image(const float* img1, const float* img2, int32_t n, int32_t c, int32_t h, int32_t w,
+                                 int32_t window, float* loss, float* d_img1, float* d_img2, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ---- optimiser (torch.optim.Adam of get_optimizer, src/train_utils.py:266) -------------- */
 /* ---- Multi-class segmentation head of the Gear/Kolektor trainers (src/metrics.py) ------------------------ */

@@ -21,6 +21,46 @@ State = Mapping[str, torch.Tensor]
 BN_EPS = 1e-5        # nn.BatchNorm2d default, /root/reference/src/model.py:15,18
 BN_MOMENTUM = 0.1
 
+# ---- optional emulation of the HIP path's bf16 STORAGE (arithmetic stays fp32, like the MFMA accumulators) ----------
+# Inside ``with bf16_storage():`` every tensor the bf16 mode of the HIP path keeps in bf16 is rounded to bf16 at the
+# point where that path stores it: convolution / transposed-convolution operands (weights, the input image) and
+# outputs, activations after ReLU, up-sampled tensors -- and, in the backward pass, the gradients of those same
+# tensors.  The reference has no bf16 mode; this is the yardstick that separates the rounding noise of the MODE (large
+# on the deep layers' gradients: ~0.3 L2-relative at N = 2) from an error of the KERNELS (tests/test_gpu_round2.py).
+_EMULATE_BF16 = False
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _q(x):
+    """a stored activation / gradient pair"""
+    return _RoundBF16.apply(x) if _EMULATE_BF16 else x
+
+
+def _qw(w):
+    """an operand that is only READ in bf16 (packed weights, the image): its gradient stays fp32"""
+    return w + (w.to(torch.bfloat16).to(w.dtype) - w).detach() if _EMULATE_BF16 else w
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _EMULATE_BF16
+        self.prev, _EMULATE_BF16 = _EMULATE_BF16, True
+        return self
+
+    def __exit__(self, *exc):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self.prev
+        return False
+
 
 # --------------------------------------------------------------------------- BN
 def batch_norm(state: State, prefix: str, x: torch.Tensor, training: bool,
@@ -55,9 +95,9 @@ def batch_norm(state: State, prefix: str, x: torch.Tensor, training: bool,
 def double_conv(state: State, prefix: str, x, training, new_stats=None):
     """(conv3x3 pad1 no-bias -> BN -> ReLU) x 2 -- model.py:13-20."""
     for conv_idx in (0, 3):
-        x = F.conv2d(x, state[f"{prefix}.double_conv.{conv_idx}.weight"], None, 1, 1)
+        x = _q(F.conv2d(x, _qw(state[f"{prefix}.double_conv.{conv_idx}.weight"]), None, 1, 1))
         x = batch_norm(state, f"{prefix}.double_conv.{conv_idx + 1}", x, training, new_stats)
-        x = torch.clamp_min(x, 0.0)
+        x = _q(torch.clamp_min(x, 0.0))
     return x
 
 
@@ -85,7 +125,7 @@ def upsample_bilinear2x(x):
     x0, x1, fx = axis(w, ow)
     top = x[:, :, y0][:, :, :, x0] * (1 - fx) + x[:, :, y0][:, :, :, x1] * fx
     bot = x[:, :, y1][:, :, :, x0] * (1 - fx) + x[:, :, y1][:, :, :, x1] * fx
-    return top * (1 - fy)[None, None, :, None] + bot * fy[None, None, :, None]
+    return _q(top * (1 - fy)[None, None, :, None] + bot * fy[None, None, :, None])
 
 
 def conv_transpose2x2(x, w, b):
@@ -93,8 +133,8 @@ def conv_transpose2x2(x, w, b):
     (weight [Cin, Cout, 2, 2])."""
     n, _, h, wd = x.shape
     co = w.shape[1]
-    y = torch.einsum("nchw,cokl->nohkwl", x, w).reshape(n, co, 2 * h, 2 * wd)
-    return y + b[None, :, None, None]
+    y = torch.einsum("nchw,cokl->nohkwl", x, _qw(w)).reshape(n, co, 2 * h, 2 * wd)
+    return _q(y + b[None, :, None, None])
 
 
 def up(state: State, prefix: str, x1, x2, training, bilinear, new_stats=None):
@@ -117,7 +157,7 @@ def out_conv(state: State, prefix: str, x):
 
 # ------------------------------------------------------------------ the models
 def _encoder(state, x, training, new_stats):
-    x1 = double_conv(state, "inc", x, training, new_stats)
+    x1 = double_conv(state, "inc", _qw(x), training, new_stats)
     x2 = down(state, "down1", x1, training, new_stats)
     x3 = down(state, "down2", x2, training, new_stats)
     x4 = down(state, "down3", x3, training, new_stats)
@@ -137,6 +177,16 @@ def unet_forward(state: State, x, training=True, bilinear=False, new_stats=None)
     """UNet.forward -- model.py:97-108: raw logits [N, n_classes, H, W]."""
     feats = _encoder(state, x, training, new_stats)
     return out_conv(state, "outc", _decoder(state, feats, "", training, bilinear, new_stats))
+
+
+def segmentation_unet_forward(state: State, x, training=True, bilinear=False, new_stats=None, drop_noise=None):
+    """SegmentationUNet.forward -- model.py:133-153: UNet with nn.Dropout2d on the bottleneck x5 (:146).
+    ``drop_noise`` [N, C] = the per-(image, channel) keep/scale factors of the dropout (None: identity, i.e. eval
+    mode or dropout=0)."""
+    x1, x2, x3, x4, x5 = _encoder(state, x, training, new_stats)
+    if drop_noise is not None:
+        x5 = x5 * drop_noise[:, :, None, None]
+    return out_conv(state, "outc", _decoder(state, (x1, x2, x3, x4, x5), "", training, bilinear, new_stats))
 
 
 def anomaly_unet_forward(state: State, x, training=True, bilinear=False, new_stats=None
@@ -221,6 +271,26 @@ def ssim_loss(img1, img2, window_size=11, size_average=True):
 def anomaly_score(recon, image):
     """compute_anomaly_score(method='mse') -- src/utils.py:205-208."""
     return ((recon - image) ** 2).mean(dim=1)
+
+
+def validate_pass(state: State, batches, recon_weight=1.0, seg_weight=1.0):
+    """The arithmetic of validate_epoch's all-one-class branch -- train_utils.py:155-204,217-227: eval-mode forward,
+    batch-size weighted mean of the three losses (:184-187), per-pixel error maps (:190), predicted masks."""
+    tot = [0.0, 0.0, 0.0]
+    count = 0
+    scores, masks_pred = [], []
+    with torch.no_grad():
+        for b in batches:
+            recon, amap = anomaly_unet_forward(state, b["image"], training=False)
+            d = combined_loss(recon, amap, b["image"], b["mask"], recon_weight, seg_weight)
+            n = b["image"].shape[0]
+            for i, k in enumerate(("total_loss", "recon_loss", "seg_loss")):
+                tot[i] += float(d[k]) * n
+            count += n
+            scores.append(anomaly_score(recon, b["image"]))
+            masks_pred.append(amap)
+    return {"total_loss": tot[0] / count, "recon_loss": tot[1] / count, "seg_loss": tot[2] / count,
+            "scores": torch.cat(scores), "masks_pred": torch.cat(masks_pred)}
 
 
 # ------------------------------------------------------- one training step

@@ -27,7 +27,11 @@ def pytest_collection_modifyitems(config, items):
 
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+        out = {}
+        for k in z.files:
+            a = np.asarray(z[k])
+            out[k] = torch.from_numpy(a) if a.dtype.kind in "fiub" else a      # (string arrays stay numpy)
+        return out
 
 
 @pytest.fixture(scope="session")

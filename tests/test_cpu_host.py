@@ -103,3 +103,25 @@ def test_mvtec_reader_contract(tmp_path):
         labels += b["label"].tolist(); mx = max(mx, float(b["mask"].max()))
     assert sorted(labels) == [0, 0, 1, 1]
     assert 0 < mx <= 1.0 / 255.0 + 1e-9, "masks are {0,1} uint8 scaled by 1/255 (reference quirk)"
+
+
+def test_shard_sampler_gives_disjoint_equal_shards():
+    """dataset.ShardSampler (data-parallel CLI): same permutation on every rank, disjoint strided shards whose union is
+    the dataset, equal length on every rank (wrap-around padding), reshuffled by set_epoch."""
+    from tiaozhanbei_unet_amd.dataset import ShardSampler
+    for n, world in ((10, 2), (11, 4), (3, 8), (64, 8)):
+        shards = []
+        for r in range(world):
+            s = ShardSampler(n, r, world, shuffle=True, seed=7)
+            s.set_epoch(3)
+            idx = list(iter(s))
+            assert len(idx) == len(s) == (n + world - 1) // world
+            shards.append(idx)
+        flat = [i for sh in shards for i in sh]
+        assert set(flat) == set(range(n))
+        assert len(flat) - len(set(flat)) == len(shards[0]) * world - n       # only the padding repeats
+        s0 = ShardSampler(n, 0, world, shuffle=True, seed=7)
+        s0.set_epoch(4)
+        if n > world:
+            assert list(iter(s0)) != shards[0]
+    assert list(iter(ShardSampler(5, 1, 2, shuffle=False))) == [1, 3, 0]

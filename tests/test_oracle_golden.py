@@ -190,3 +190,78 @@ def test_adam_trajectory():
     close(torch.tensor(losses), g["losses"], 2e-4, 2e-4, "loss trajectory")
     for k in ("outc_seg.conv.weight", "outc_recon.conv.bias", "inc.double_conv.1.running_mean"):
         close(state[k], g["final:" + k], 5e-4, 1e-3, k)
+
+
+# ------------------------------------------------------------------ round-2 fixtures (tools/make_goldens_r2.py)
+def _val_batches():
+    out = []
+    for i, n in enumerate((2, 2, 1)):
+        out.append({"image": W.make_input(f"val:image{i}", (n, 3, 32, 32)), "mask": torch.zeros(n, 1, 32, 32),
+                    "label": torch.zeros(n, dtype=torch.long)})
+    return out
+
+
+def test_validate_epoch_all_normal_branch():
+    """validate_epoch (reference train_utils.py:155-260) on a seeded all-normal loader: weighted losses, score maps."""
+    g = load_golden("validate_epoch_all_normal")
+    state = W.make_state(W.state_spec("anomaly_unet", 3, 1, False), 0)
+    r = O.validate_pass(state, _val_batches())
+    for k in ("total_loss", "recon_loss", "seg_loss"):
+        assert abs(r[k] - float(g[k])) < 2e-6 * max(1.0, abs(float(g[k]))), k
+    close(r["scores"], g["scores"], 1e-6, 1e-5, what="score maps")
+    close(r["masks_pred"], g["masks_pred"], 1e-6, what="predicted masks")
+    assert tuple(g["scores"].shape) == (5, 32, 32) and list(g["labels"]) == [0] * 5
+
+
+@pytest.mark.parametrize("c,hw", [(3, (40, 36)), (1, (20, 50))])
+def test_ssim_per_image(c, hw):
+    """SSIMLoss(size_average=False) (reference train_utils.py:84-87): one loss per image."""
+    g = load_golden(f"ssim_noavg_c{c}_{hw[0]}x{hw[1]}")
+    a = W.make_input(f"ssim:a{c}", (2, c) + hw, kind="uniform").requires_grad_(True)
+    b = W.make_input(f"ssim:b{c}", (2, c) + hw).requires_grad_(True)
+    v = O.ssim_loss(a, b, size_average=False)
+    assert tuple(v.shape) == (2,)
+    close(v, g["value"], 2e-6, what="per-image ssim loss")
+    (v * g["gy"]).sum().backward()
+    close(a.grad, g["d_img1"], 1e-7, 1e-4, "d_img1")
+    close(b.grad, g["d_img2"], 1e-7, 1e-4, "d_img2")
+
+
+@pytest.mark.parametrize("sz,shape", [("s32", (2, 3, 32, 32)), ("s36x52", (1, 3, 36, 52))])
+def test_segmentation_unet_forward(sz, shape):
+    """SegmentationUNet (reference model.py:111-153): eval forward and train forward with dropout 0; argmax exact."""
+    g = load_golden(f"model_segunet_3_4_{sz}")
+    state = W.make_state(W.state_spec("unet", 3, 4, False), 0)
+    x = W.make_input(f"model:{sz}", shape)
+    with torch.no_grad():
+        ev = O.segmentation_unet_forward(state, x, training=False)
+        tr = O.segmentation_unet_forward(dict(state), x, training=True, new_stats={})
+    close(ev, g["eval_out"], 2e-5, what="eval logits")
+    close(tr, g["train_out_nodrop"], 2e-5, what="train logits")
+    assert torch.equal(ev.argmax(1).to(torch.uint8), g["eval_argmax"])
+    assert torch.equal(tr.argmax(1).to(torch.uint8), g["train_argmax_nodrop"])
+
+
+def test_unet_seg_only_training_step():
+    """BASELINE configs[1]: UNet(3,1) trained on focal(sigmoid(logits)) alone -- gradients of step 1 and the 3-step
+    Adam loss trajectory of the reference."""
+    g = load_golden("train_unet_segonly")
+    state = W.make_state(W.state_spec("unet", 3, 1, False), 0)
+    image = W.make_input("segonly:image", (2, 3, 32, 32))
+    mask = W.make_input("segonly:mask", (2, 1, 32, 32), kind="bernoulli")
+    work = {k: (v.clone().requires_grad_(True) if O.is_trainable(k) else v) for k, v in state.items()}
+    amap = torch.sigmoid(O.unet_forward(work, image, True))
+    close(amap, g["amap"], 2e-6, what="probabilities")
+    loss = O.focal_loss(amap, mask)
+    loss.backward()
+    assert abs(float(loss) - float(g["losses"][0, 2])) < 1e-6
+    for k in ("inc.double_conv.0.weight", "up4.conv.double_conv.3.weight", "outc.conv.weight", "outc.conv.bias"):
+        ref = g["grad:" + k]
+        rel = float((work[k].grad.double() - ref.double()).norm() / ref.double().norm())
+        assert rel < 2e-3, f"{k}: {rel:.3e}"
+    opt, losses = {}, []
+    st = dict(state)
+    for _ in range(3):
+        st, d = O.train_step(st, opt, image, mask, model="unet", recon_weight=0.0)
+        losses.append(d["total_loss"])
+    assert float((torch.tensor(losses) - g["losses"][:, 0].float()).abs().max()) < 2e-4, losses

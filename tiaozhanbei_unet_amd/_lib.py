@@ -37,6 +37,7 @@ SIGNATURES = {
     "unet_last_error": (C.c_char_p, []),
     "unet_prof_enable": (_i, [_i]),
     "unet_prof_collect": (_i, [_p, _p, _p]),
+    "unet_prof_kernel_stats": (_i, [_i, _p, _p, _p, _p]),
     "unet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_pack_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -62,6 +63,8 @@ SIGNATURES = {
     "unet_bn_workspace": (_z, [_l, _i]),
     "unet_bn_train_stats": (_i, [_i, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
     "unet_bn_eval_coeffs": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "unet_bn_eval_coeffs4": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "unet_bn_relu_bwd_frozen": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "unet_bn_relu_apply": (_i, [_i, _p, _l, _i, _p, _p, _p, _p]),
     "unet_bn_relu_bwd": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "unet_bn_bwd_premasked": (_i, [_i, _p, _p, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
@@ -79,6 +82,7 @@ SIGNATURES = {
     "unet_loss_mse_focal": (_i, [_p, _p, _l, _p, _p, _l, _f, _f, _p, _p, _p, _p, _z, _p]),
     "unet_ssim_workspace": (_z, [_i, _i, _i]),
     "unet_ssim_loss": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "unet_ssim_loss_per_image": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "unet_seg_loss_workspace": (_z, [_i, _i, _l]),
     "unet_seg_loss": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _f, _f, _f, _f, _f, _p, _p, _p, _z, _p]),
     "unet_seg_confusion": (_i, [_p, _p, _i, _i, _l, _l, _p, _p, _p]),

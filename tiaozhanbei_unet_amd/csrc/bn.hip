@@ -166,15 +166,17 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
   double s, ss;
   sum_parts_t<TL, TC>(part, nparts, C, c, rl, red, s, ss);
   if (rl != 0) return;
-  if (raw) ss *= (double)istd[c];          // partials hold sum dz * (y - mean): normalise here
+  if (raw & 1) ss *= (double)istd[c];      // partials hold sum dz * (y - mean): normalise here
   const float db = (float)s, dg = (float)ss;
   dbeta[c] = db;
   dgamma[c] = dg;
   const float A = gamma[c] * istd[c];
-  const float B = -A * istd[c] * dg * inv_count;
+  // bit 1: frozen statistics (BatchNorm in eval mode inside a training graph): mean / istd are constants, the
+  // two batch-statistics terms of the input gradient vanish
+  const float B = (raw & 2) ? 0.f : -A * istd[c] * dg * inv_count;
   coefs[c] = A;
   coefs[C + c] = B;
-  coefs[2 * C + c] = -A * db * inv_count - B * mean[c];
+  coefs[2 * C + c] = (raw & 2) ? 0.f : -A * db * inv_count - B * mean[c];
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C,
@@ -187,13 +189,15 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm,
-                                      const float* rv, float eps, float* scale, float* shift) {
+                                      const float* rv, float eps, float* scale, float* shift, float* mean_out,
+                                      float* istd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float istd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
   const float sc = gamma[c] * istd;
   scale[c] = sc;
   shift[c] = fmaf(-rm[c], sc, beta[c]);
+  if (mean_out) { mean_out[c] = rm[c]; istd_out[c] = istd; }
 }
 
 // FAST: (256*PIECE) % C == 0, so a thread's channel group never changes along the grid-stride loop and its
@@ -469,7 +473,17 @@ extern "C" int32_t unet_bn_eval_coeffs(int32_t c, const float* gamma, const floa
   UNET_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && c > 0, UNET_ERR_BAD_ARG,
                "unet_bn_eval_coeffs: bad argument");
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c, gamma, beta,
-                     running_mean, running_var, eps, scale, shift);
+                     running_mean, running_var, eps, scale, shift, (float*)nullptr, (float*)nullptr);
+  return unet_check_launch("bn_eval_coeffs_kernel");
+}
+
+extern "C" int32_t unet_bn_eval_coeffs4(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                                        const float* running_var, float eps, float* mean, float* istd, float* scale,
+                                        float* shift, void* stream) {
+  UNET_REQUIRE(gamma && beta && running_mean && running_var && mean && istd && scale && shift && c > 0, UNET_ERR_BAD_ARG,
+               "unet_bn_eval_coeffs4: bad argument");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, mean, istd);
   return unet_check_launch("bn_eval_coeffs_kernel");
 }
 
@@ -499,10 +513,10 @@ extern "C" int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixe
   return unet_check_launch("bn_relu_apply_kernel");
 }
 
-extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
-                                    const float* gamma, const float* save_mean, const float* save_istd,
-                                    const float* scale, const float* shift, float* dgamma, float* dbeta,
-                                    void* dy, void* workspace, size_t workspace_bytes, void* stream) {
+static int32_t bn_relu_bwd_impl(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                                const float* gamma, const float* save_mean, const float* save_istd,
+                                const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                void* dy, void* workspace, size_t workspace_bytes, void* stream, int frozen) {
   UNET_REQUIRE(da && y && gamma && save_mean && save_istd && scale && shift && dgamma && dbeta && dy && workspace,
                UNET_ERR_BAD_ARG, "unet_bn_relu_bwd: null pointer");
   UNET_REQUIRE(pixels > 0 && c > 0 && c % 64 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_relu_bwd: c=%d", c);
@@ -521,10 +535,10 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
   const float inv = (float)(1.0 / (double)pixels);
   if (pl.nparts >= 128)      // latency-bound: 64 partial-lanes per channel
     hipLaunchKernelGGL((bn_finalize_bwd_kernel<64, 4>), dim3(c / 4), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
-                       save_mean, save_istd, dgamma, dbeta, coefs, 0);
+                       save_mean, save_istd, dgamma, dbeta, coefs, frozen ? 2 : 0);
   else
     hipLaunchKernelGGL((bn_finalize_bwd_kernel<FL, FC>), dim3(c / FC), dim3(256), 0, s, part, pl.nparts, c, inv, gamma,
-                       save_mean, save_istd, dgamma, dbeta, coefs, 0);
+                       save_mean, save_istd, dgamma, dbeta, coefs, frozen ? 2 : 0);
   rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
   if (dtype == UNET_BF16) {
@@ -545,6 +559,22 @@ extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y
                          (const float*)da, (const float*)y, pieces, c, scale, shift, coefs, (float*)dy);
   }
   return unet_check_launch("bn_relu_bwd_apply_kernel");
+}
+
+extern "C" int32_t unet_bn_relu_bwd(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                                    const float* gamma, const float* save_mean, const float* save_istd,
+                                    const float* scale, const float* shift, float* dgamma, float* dbeta,
+                                    void* dy, void* workspace, size_t workspace_bytes, void* stream) {
+  return bn_relu_bwd_impl(dtype, da, y, pixels, c, gamma, save_mean, save_istd, scale, shift, dgamma, dbeta, dy, workspace,
+                          workspace_bytes, stream, 0);
+}
+
+extern "C" int32_t unet_bn_relu_bwd_frozen(int32_t dtype, const void* da, const void* y, int64_t pixels, int32_t c,
+                                           const float* gamma, const float* mean, const float* istd, const float* scale,
+                                           const float* shift, float* dgamma, float* dbeta, void* dy, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  return bn_relu_bwd_impl(dtype, da, y, pixels, c, gamma, mean, istd, scale, shift, dgamma, dbeta, dy, workspace,
+                          workspace_bytes, stream, 1);
 }
 
 extern "C" int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const void* y, int64_t pixels, int32_t c,

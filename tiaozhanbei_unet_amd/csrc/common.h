@@ -31,11 +31,13 @@ int32_t unet_check_launch(const char* what);
 
 // ---- per-class event timing (prof.cpp) ---------------------------------------------------
 void unet_prof_begin(int kclass, hipStream_t s);
-void unet_prof_end(int kclass, double flops, hipStream_t s);
+void unet_prof_end(int kclass, double flops, hipStream_t s, const char* kernel);
 struct ProfScope {
-  int k; double f; hipStream_t s;
-  ProfScope(int kclass, double flops, hipStream_t st) : k(kclass), f(flops), s(st) { unet_prof_begin(k, s); }
-  ~ProfScope() { unet_prof_end(k, f, s); }
+  int k; double f; hipStream_t s; const char* name;      // name: static string naming the (dominant) kernel of the bracket
+  ProfScope(int kclass, double flops, hipStream_t st, const char* kernel = nullptr) : k(kclass), f(flops), s(st), name(kernel) {
+    unet_prof_begin(k, s);
+  }
+  ~ProfScope() { unet_prof_end(k, f, s, name); }
 };
 
 // deterministic per-channel sum of x[pixels][C] (bn.hip); ws is scratch

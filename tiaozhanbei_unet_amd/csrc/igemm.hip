@@ -853,13 +853,13 @@ int32_t launch3(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_par
         attr_m = true;
       }
       if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;   // epilogue writes the BN partials
-      ProfScope prof(kclass, flops, s);
+      ProfScope prof(kclass, flops, s, "conv3m16_kernel");
       hipLaunchKernelGGL(km, dim3((unsigned)blocks), dim3(256), CM::LDS, s, P);
       return unet_check_launch("conv3m16_kernel");
     }
   }
   P.stats = nullptr;
-  ProfScope prof(kclass, flops, s);
+  ProfScope prof(kclass, flops, s, "conv3_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
   return unet_check_launch("conv3_kernel");
 }
@@ -1385,7 +1385,8 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
 #ifdef PDMA_STAMPS
   if (!bnbwd) P.bn_mean = (const float*)g_pdma_debug;
 #endif
-  ProfScope prof(kclass, flops, s);
+  ProfScope prof(kclass, flops, s, bnbwd ? (BN == 128 ? "conv3_pdma128_bnbwd_kernel" : "conv3_pdma64_bnbwd_kernel")
+                                          : (BN == 128 ? "conv3_pdma128_kernel" : "conv3_pdma64_kernel"));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("conv3_pdma_kernel");
 }
@@ -1665,7 +1666,7 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   P.stats = nullptr;   // 144 weight VGPRs leave no room for per-lane running sums: BN partials by the streaming pass
   (void)stat_parts;
-  ProfScope prof(kclass, flops, s);
+  ProfScope prof(kclass, flops, s, "conv3_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P, tpb);
   return unet_check_launch("conv3_ws_kernel");
 }
@@ -1873,7 +1874,7 @@ int32_t launch_convt_ws(ConvTParams P, hipStream_t s) {
   P.tiles_per_block = tpb;
   const long long ranges8 = cdiv64(cdiv64(P.tiles, tpb), 8) * 8;
   const double flops = 2.0 * total_px * 4.0 * P.Cout * CIN;
-  ProfScope prof(UNET_K_CONVT_FWD, flops, s);
+  ProfScope prof(UNET_K_CONVT_FWD, flops, s, "convt_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)(ranges8 * nCg)), dim3(512), C::LDS, s, P);
   return unet_check_launch("convt_ws_kernel");
 }
@@ -2036,7 +2037,7 @@ int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s) {
   P.tiles_per_block = tpb;
   const long long blocks = cdiv64(P.tiles, tpb);
   const double flops = 2.0 * total_px * 4.0 * COUT * C::CIN;
-  ProfScope prof(UNET_K_CONVT_DGRAD, flops, s);
+  ProfScope prof(UNET_K_CONVT_DGRAD, flops, s, "convt_dgrad_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("convt_dgrad_ws_kernel");
 }
@@ -2055,9 +2056,19 @@ int32_t launch(const IgemmParams& Pin, int kclass, hipStream_t s) {
   const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo * P.nZ;
   UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "igemm: grid of %lld blocks", blocks);
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * TAPS * P.gtaps * P.nZ;
-  ProfScope prof(kclass, flops, s);
+  ProfScope prof(kclass, flops, s, "igemm_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS, s, P);
   return unet_check_launch("igemm_kernel");
+}
+
+// The specialised 3x3 kernels address one image plane of every view with 32-bit buffer offsets (descriptor
+// num_records and voffset): a plane of 2 GiB or more (e.g. 4096x4096x64 bf16) must take the generic kernel, whose
+// addressing is 64-bit.
+template <typename T>
+inline bool planes_fit_32bit(const IgemmParams& P) {
+  auto ok = [](long long h, long long w, long long c) { return h * w * c * (long long)sizeof(T) < 0x7FFFFFFFLL; };
+  return ok(P.src[0].H, P.src[0].W, P.src[0].C) && ok(P.src[1].H, P.src[1].W, P.src[1].C) &&
+         ok(P.dst[0].H, P.dst[0].W, P.dst[0].C) && ok(P.dst[1].H, P.dst[1].W, P.dst[1].C);
 }
 
 template <typename T, int TAPS>
@@ -2077,17 +2088,18 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nu
   P.tilesY = cdiv(P.H, TH);
   static const char* impl_env = nullptr;
   impl_env = getenv("UNET_CONV_IMPL");          // tuning hook: "0" = generic igemm_kernel, default conv3_kernel
-  const bool use3 = !(impl_env && impl_env[0] == '0');
+  const bool small = planes_fit_32bit<T>(P);
+  const bool use3 = small && !(impl_env && impl_env[0] == '0');
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // 64-channel inputs: weight-stationary streaming kernel (impl "2" forces it off)
-    const bool ws_ok = P.Ctot == 64 && P.src[1].C == 0 &&
+    const bool ws_ok = small && P.Ctot == 64 && P.src[1].C == 0 &&
                        !(impl_env && (impl_env[0] == '0' || impl_env[0] == '2'));
     if (ws_ok) return launch_ws(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // deep layers (>= 4 input chunks: below that the un-overlapped prologue of the one block per CU costs more
     // than it saves): both operands by LDS-DMA, 512-thread blocks (impl "3" = the register-staged kernels)
-    const bool dma_ok = k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 &&
+    const bool dma_ok = small && k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 &&
                         !(impl_env && (impl_env[0] == '0' || impl_env[0] == '3'));
     if (dma_ok) return big ? launch_pdma<128>(P, kclass, s, stat_parts) : launch_pdma<64>(P, kclass, s, stat_parts);
   }

@@ -288,3 +288,20 @@ extern "C" int32_t unet_ssim_loss(const float* img1, const float* img2, int32_t 
                      (const float*)maps, map_stride, d_img1, d_img2);
   return unet_check_launch("ssim_bwd_kernel");
 }
+
+// SSIMLoss(size_average=False) (train_utils.py:84-87): loss[i] = 1 - mean over (C, H, W) of image i's SSIM map;
+// d_img1 / d_img2 hold d loss[i] / d img for image i (the caller scales image i's slice by its upstream gradient).
+// One pass of the same kernels per image (planes = channels): the workspace of ONE image is reused in stream order.
+extern "C" int32_t unet_ssim_loss_per_image(const float* img1, const float* img2, int32_t n, int32_t c, int32_t h, int32_t w,
+                                            int32_t window, float* loss, float* d_img1, float* d_img2, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(n > 0 && c > 0, UNET_ERR_BAD_ARG, "unet_ssim_loss_per_image: bad dims");
+  const size_t img = (size_t)c * h * w;
+  for (int i = 0; i < n; ++i) {
+    const int32_t rc = unet_ssim_loss(img1 + i * img, img2 + i * img, c, h, w, window, loss + i,
+                                      d_img1 ? d_img1 + i * img : nullptr, d_img2 ? d_img2 + i * img : nullptr, workspace,
+                                      workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return UNET_OK;
+}

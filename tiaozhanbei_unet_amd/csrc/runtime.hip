@@ -30,7 +30,9 @@ extern "C" const char* unet_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------ profiling
 namespace {
-struct Rec { int k; double flops; hipEvent_t a, b; };
+struct Rec { int k; double flops; hipEvent_t a, b; const char* name; };
+struct KStat { const char* name; double ms; long long launches; double flops; };
+std::vector<KStat> g_kstats;                      // per-kernel aggregation of the last unet_prof_collect()
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -52,13 +54,13 @@ void unet_prof_begin(int, hipStream_t s) {
   if (t_start) (void)hipEventRecord(t_start, s);
 }
 
-void unet_prof_end(int k, double flops, hipStream_t s) {
+void unet_prof_end(int k, double flops, hipStream_t s, const char* kernel) {
   if (!g_on || !t_start) return;
   std::lock_guard<std::mutex> l(g_mu);
   hipEvent_t b = get_event();
   if (!b) return;
   (void)hipEventRecord(b, s);
-  g_recs.push_back({k, flops, t_start, b});
+  g_recs.push_back({k, flops, t_start, b, kernel});
   t_start = nullptr;
 }
 
@@ -72,15 +74,31 @@ extern "C" int32_t unet_prof_collect(double* ms, int64_t* launches, double* flop
   UNET_REQUIRE(ms && launches && flops, UNET_ERR_BAD_ARG, "unet_prof_collect: null output");
   std::lock_guard<std::mutex> l(g_mu);
   for (int i = 0; i < UNET_K_COUNT; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; }
+  g_kstats.clear();
   for (auto& r : g_recs) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess &&
         r.k >= 0 && r.k < UNET_K_COUNT) {
       ms[r.k] += t; launches[r.k] += 1; flops[r.k] += r.flops;
+      if (r.name) {
+        KStat* ks = nullptr;
+        for (auto& e : g_kstats) if (e.name == r.name || strcmp(e.name, r.name) == 0) { ks = &e; break; }
+        if (!ks) { g_kstats.push_back({r.name, 0.0, 0, 0.0}); ks = &g_kstats.back(); }
+        ks->ms += t; ks->launches += 1; ks->flops += r.flops;
+      }
     }
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
   g_recs.clear();
+  return UNET_OK;
+}
+
+extern "C" int32_t unet_prof_kernel_stats(int32_t index, const char** name, double* ms, int64_t* launches, double* flops) {
+  UNET_REQUIRE(name && ms && launches && flops, UNET_ERR_BAD_ARG, "unet_prof_kernel_stats: null output");
+  std::lock_guard<std::mutex> l(g_mu);
+  UNET_REQUIRE(index >= 0 && index < (int)g_kstats.size(), UNET_ERR_BAD_ARG, "unet_prof_kernel_stats: index %d of %zu", index,
+               g_kstats.size());
+  *name = g_kstats[index].name; *ms = g_kstats[index].ms; *launches = g_kstats[index].launches; *flops = g_kstats[index].flops;
   return UNET_OK;
 }

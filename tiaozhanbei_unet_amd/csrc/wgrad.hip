@@ -477,7 +477,7 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
   const long long blocks = (long long)pl.split * pl.nR * pl.nC;
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
   {
-    ProfScope prof(kclass, flops, s);
+    ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)");
     const char* impl = getenv("UNET_WGRAD_IMPL");               // tuning hook: "0" = register-staged kernel
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
       if (!(impl && impl[0] == '0')) {
@@ -772,7 +772,7 @@ int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w
     attr_done = true;
   }
   {
-    ProfScope prof(UNET_K_CONVT_WGRAD, 2.0 * px * 4.0 * C::COUT * CIN, s);
+    ProfScope prof(UNET_K_CONVT_WGRAD, 2.0 * px * 4.0 * C::COUT * CIN, s, "convt_wgrad_ws_kernel (+ reduce)");
     hipLaunchKernelGGL(kern, dim3(nsplit, yb), dim3(256), C::LDS, s, P);
     int32_t rc = unet_check_launch("convt_wgrad_ws_kernel");
     if (rc) return rc;

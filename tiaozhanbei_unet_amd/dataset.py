@@ -77,10 +77,49 @@ class MVTecDataset(Dataset):
                 "label": self.labels[i], "anomaly_type": self.anomaly_types[i], "image_path": self.image_paths[i]}
 
 
-def get_dataloaders(root_dir, category, batch_size=16, image_size=256, num_workers=4):
+class ShardSampler(torch.utils.data.Sampler):
+    """Per-rank shard of a dataset for data-parallel training (rank r trains on its own images).
+
+    Every epoch all ranks draw the SAME permutation (seed + epoch), pad it by wrap-around to a multiple of the world
+    size -- so every rank runs the same number of steps and no collective is left waiting -- and rank r takes indices
+    r, r + world, r + 2*world, ...: disjoint shards whose union is the dataset.  Call ``set_epoch`` before each epoch."""
+
+    def __init__(self, n, rank=0, world=1, shuffle=True, seed=0):
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = int(n), rank, world, shuffle, seed, 0
+        self.per_rank = (self.n + world - 1) // world
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def indices(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        total = self.per_rank * self.world
+        while len(order) < total:
+            order += order[:total - len(order)]
+        return order[self.rank:total:self.world]
+
+    def __iter__(self):
+        return iter(self.indices())
+
+    def __len__(self):
+        return self.per_rank
+
+
+def get_dataloaders(root_dir, category, batch_size=16, image_size=256, num_workers=4, rank=0, world=1, seed=0):
+    """(train_loader, test_loader) like the reference's (src/dataset.py:157-199).  With ``world > 1`` the train loader
+    draws from this rank's ShardSampler shard (``loader.sampler.set_epoch(e)`` reshuffles); the test loader is whole."""
     train = MVTecDataset(root_dir, category, "train", image_size, is_train=True)
     test = MVTecDataset(root_dir, category, "test", image_size, is_train=False)
     kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available())
+    if world > 1:
+        sampler = ShardSampler(len(train), rank, world, shuffle=True, seed=seed)
+        return DataLoader(train, sampler=sampler, **kw), DataLoader(test, shuffle=False, **kw)
     return DataLoader(train, shuffle=True, **kw), DataLoader(test, shuffle=False, **kw)
 
 

@@ -120,6 +120,16 @@ class SegmentationMetrics:
             return self._host_cm + self._dev_cm.cpu().numpy()
         return self._host_cm
 
+    @confusion_matrix.setter
+    def confusion_matrix(self, value):
+        """The reference's attribute is a plain numpy array callers may assign or ``+=`` (metrics.py:19,44): an
+        assignment replaces the counts held so far (device-side counts included)."""
+        value = np.asarray(value, dtype=np.int64)
+        if value.shape != (self.num_classes, self.num_classes):
+            raise ValueError(f"confusion matrix must be {self.num_classes}x{self.num_classes}, got {value.shape}")
+        self._host_cm = value.copy()
+        self._dev_cm = None
+
     def update(self, pred, target):
         """pred: (N, C, H, W) scores or (N, H, W) labels; target: (N, H, W) labels."""
         _require_cuda(pred, target)

@@ -364,9 +364,10 @@ def _bn_stats_conv(lib, dt, n, h, w, src, wp, co, y, gamma, beta, running_mean, 
             "unet_bn_finalize_partials")
 
 
-def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, st):
+def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, st, frozen=False):
     """Gradient w.r.t. the raw conv output of a conv-BN-ReLU layer -> (dy, dgamma/dbeta [2, C]).  Premasked path: the
-    consumer's data-gradient kernel already applied the ReLU mask and reduced the BatchNorm-backward sums (BnLink)."""
+    consumer's data-gradient kernel already applied the ReLU mask and reduced the BatchNorm-backward sums (BnLink).
+    ``frozen``: the layer normalised with its running statistics (BatchNorm2d in eval mode inside a training graph)."""
     n, co, h, w = y.shape
     pixels = n * h * w
     dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
@@ -385,9 +386,10 @@ def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, s
         da = _as_nhwc(da, dtype)
         dy = _nhwc_empty(n, co, h, w, dtype, dev)
         ws = _workspace(lib.unet_bn_workspace(pixels, co), dev)
-        L.check(lib.unet_bn_relu_bwd(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
-                                     _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
-                                     _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
+        fn = lib.unet_bn_relu_bwd_frozen if frozen else lib.unet_bn_relu_bwd
+        L.check(fn(dt, _ptr(da), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
+                   _ptr(coef[2]), _ptr(coef[3]), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dy),
+                   _ptr(ws), ws.numel(), st), "unet_bn_relu_bwd")
     if link is not None:
         link.y = link.coef = link.partial = None
         link.dz_ptr = 0
@@ -449,8 +451,9 @@ class ConvBnRelu(torch.autograd.Function):
         else:
             dst = _views([(y, 0, 0), None])
             L.check(lib.unet_conv3x3(dt, n, h, w, src, _ptr(wp), co, dst, co, 0, L.K_CONV_FWD, st), "unet_conv3x3")
-            L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                            BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
+            L.check(lib.unet_bn_eval_coeffs4(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                             BN_EPS, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
+                    "unet_bn_eval_coeffs4")
         ctx.geom = (oy, ox, training)
         ctx.sink0 = getattr(x0, "_unet_sink", None)     # x0 is a skip with a shared gradient buffer
         ctx.out_sink = None                              # set by share_grad() when THIS output is a skip
@@ -479,8 +482,6 @@ class ConvBnRelu(torch.autograd.Function):
         saved = ctx.saved_tensors
         x0, x1, y, weight, gamma, coef = saved[:6]
         oy, ox, training = ctx.geom
-        if not training:
-            raise RuntimeError("backward through BatchNorm in eval mode is not on the hot path (unsupported)")
         dtype = x0.dtype
         dt = _DT[dtype]
         n, c0, h, w = x0.shape
@@ -511,7 +512,8 @@ class ConvBnRelu(torch.autograd.Function):
                                               _ptr(coef[1]), _ptr(part), nparts.value, _ptr(dgb[0]), _ptr(dgb[1]),
                                               _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
         else:
-            dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, ctx.out_sink, dev, st)
+            dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, ctx.out_sink, dev, st,
+                                        frozen=not training)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         dw = None
         wgrad_done = None
@@ -602,8 +604,9 @@ class FirstConvBnRelu(torch.autograd.Function):
         else:
             L.check(lib.unet_conv3x3_first_stats(n, h, w, _ptr(x), ci, _ptr(wq), _ptr(y), None, None, st),
                     "unet_conv3x3_first_stats")
-            L.check(lib.unet_bn_eval_coeffs(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                            BN_EPS, _ptr(coef[2]), _ptr(coef[3]), st), "unet_bn_eval_coeffs")
+            L.check(lib.unet_bn_eval_coeffs4(co, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                             BN_EPS, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
+                    "unet_bn_eval_coeffs4")
         a = _nhwc_empty(n, co, h, w, dtype, dev)
         L.check(lib.unet_bn_relu_apply(_DT[dtype], _ptr(y), pixels, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(a), st),
                 "unet_bn_relu_apply")
@@ -619,14 +622,13 @@ class FirstConvBnRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, da):
         x, y, weight, gamma, coef = ctx.saved_tensors
-        if not ctx.training:
-            raise RuntimeError("backward through BatchNorm in eval mode is not on the hot path (unsupported)")
         dtype = torch.bfloat16
         dt = _DT[dtype]
         n, ci, h, w = x.shape
         co = weight.shape[0]
         lib, st, dev = L.lib(), _stream(), x.device
-        dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, ctx.out_link, ctx.out_sink, dev, st)
+        dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, ctx.out_link, ctx.out_sink, dev, st,
+                                    frozen=not ctx.training)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=torch.float32)
@@ -847,29 +849,40 @@ class MseFocal(torch.autograd.Function):
 
 
 class Ssim(torch.autograd.Function):
-    """SSIMLoss.forward (/root/reference/src/train_utils.py:89-104), size_average=True."""
+    """SSIMLoss.forward (/root/reference/src/train_utils.py:89-104): a 0-d loss (size_average=True) or one value per
+    image (size_average=False, :84-87)."""
 
     @staticmethod
-    def forward(ctx, img1, img2, window_size):
+    def forward(ctx, img1, img2, window_size, size_average=True):
         _require_cuda(img1, img2)
         img1, img2 = img1.contiguous().float(), img2.contiguous().float()
         n, c, h, w = img1.shape
         lib, dev = L.lib(), img1.device
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         d1 = torch.empty_like(img1) if need else None
         d2 = torch.empty_like(img2) if need else None
-        ws = _workspace(lib.unet_ssim_workspace(n * c, h, w), dev)
-        L.check(lib.unet_ssim_loss(_ptr(img1), _ptr(img2), n * c, h, w, int(window_size), _ptr(loss), _ptr(d1),
-                                   _ptr(d2), _ptr(ws), ws.numel(), _stream()), "unet_ssim_loss")
+        ctx.per_image = not size_average
+        if size_average:
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            ws = _workspace(lib.unet_ssim_workspace(n * c, h, w), dev)
+            L.check(lib.unet_ssim_loss(_ptr(img1), _ptr(img2), n * c, h, w, int(window_size), _ptr(loss), _ptr(d1),
+                                       _ptr(d2), _ptr(ws), ws.numel(), _stream()), "unet_ssim_loss")
+        else:
+            loss = torch.empty(n, dtype=torch.float32, device=dev)
+            ws = _workspace(lib.unet_ssim_workspace(c, h, w), dev)
+            L.check(lib.unet_ssim_loss_per_image(_ptr(img1), _ptr(img2), n, c, h, w, int(window_size), _ptr(loss),
+                                                 _ptr(d1), _ptr(d2), _ptr(ws), ws.numel(), _stream()),
+                    "unet_ssim_loss_per_image")
         if need:
             ctx.save_for_backward(d1, d2)
-        return loss[0]
+        return loss[0] if size_average else loss
 
     @staticmethod
     def backward(ctx, g):
         d1, d2 = ctx.saved_tensors
-        return d1 * g, d2 * g, None
+        if ctx.per_image:
+            g = g.reshape(-1, 1, 1, 1)
+        return d1 * g, d2 * g, None, None
 
 
 # ----------------------------------------------------------------------------- profiling / optimiser
@@ -884,6 +897,19 @@ def prof_collect():
     L.check(L.lib().unet_prof_collect(ms, launches, flops), "unet_prof_collect")
     return {L.KCLASS_NAMES[i]: {"ms": ms[i], "launches": launches[i], "flops": flops[i]}
             for i in range(L.K_COUNT)}
+
+
+def prof_kernels():
+    """Per-kernel breakdown of the brackets consumed by the last prof_collect(): {kernel name: ms, launches, flops}."""
+    out, i = {}, 0
+    lib = L.lib()
+    while True:
+        name, ms, n, fl = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double()
+        if lib.unet_prof_kernel_stats(i, C.byref(name), C.byref(ms), C.byref(n), C.byref(fl)) != 0:
+            break
+        out[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
+        i += 1
+    return out
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):

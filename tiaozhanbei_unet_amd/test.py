@@ -47,7 +47,7 @@ def test_model(model, test_loader, device, threshold=None):
             if isinstance(model, AnomalyUNet):
                 recon, amap = model(images)
             else:
-                amap, recon = torch.sigmoid(model(images)), images
+                amap, recon = model(images, sigmoid=True), images      # sigmoid inside the head kernel
             out["anomaly_scores"].extend(compute_anomaly_score(recon, images).cpu().numpy())
             out["images"].extend(images.cpu()); out["reconstructions"].extend(recon.cpu())
             out["anomaly_maps"].extend(amap.cpu().numpy()); out["masks_true"].extend(batch["mask"].numpy())

@@ -65,7 +65,7 @@ class _SegOnly(torch.nn.Module):
         self.unet = unet
 
     def forward(self, x):
-        return x, torch.sigmoid(self.unet(x))
+        return x, self.unet(x, sigmoid=True)          # sigmoid inside the head kernel (ops.Head / fused head)
 
 
 def main(argv=None):
@@ -95,21 +95,32 @@ def main(argv=None):
         return
 
     stamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+    if world > 1:                                   # one run directory: rank 0's time stamp
+        box = [stamp]
+        torch.distributed.broadcast_object_list(box, src=0)
+        stamp = box[0]
     exp_dir = os.path.join(args.save_dir, f"{args.category}_{args.model}_{stamp}")
     dirs = create_output_dirs(exp_dir)
     if rank == 0:
         with open(os.path.join(exp_dir, "args.json"), "w") as f:
             json.dump(vars(args), f, indent=2)
 
+    # data parallel: every rank trains on its own shard (dataset.ShardSampler: same permutation on every rank, strided
+    # shards padded to equal length), validation runs on rank 0 over the whole test split
     train_loader, val_loader = get_dataloaders(args.data_root, args.category, args.batch_size, args.image_size,
-                                               args.num_workers)
+                                               args.num_workers, rank=rank, world=world, seed=args.seed)
     if args.debug:
         import random
         from torch.utils.data import DataLoader, Subset
-        def limit(loader, shuffle):
-            idx = random.sample(range(len(loader.dataset)), min(args.debug_samples, len(loader.dataset)))
-            return DataLoader(Subset(loader.dataset, idx), batch_size=args.batch_size, shuffle=shuffle,
-                              num_workers=args.num_workers, pin_memory=True)
+        from .dataset import ShardSampler
+        picker = random.Random(args.seed)           # the same subset on every rank
+        def limit(loader, train):
+            idx = picker.sample(range(len(loader.dataset)), min(args.debug_samples, len(loader.dataset)))
+            sub = Subset(loader.dataset, idx)
+            kw = dict(batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=True)
+            if train and world > 1:
+                return DataLoader(sub, sampler=ShardSampler(len(sub), rank, world, True, args.seed), **kw)
+            return DataLoader(sub, shuffle=train, **kw)
         train_loader, val_loader = limit(train_loader, True), limit(val_loader, False)
     say(f"Train samples: {len(train_loader.dataset)}\nValidation samples: {len(val_loader.dataset)}")
 
@@ -136,15 +147,22 @@ def main(argv=None):
     train_losses, val_losses, best = [], [], float("inf")
     for epoch in range(start_epoch, args.epochs):
         t0 = time.time()
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
         tm = train_epoch(net, train_loader, criterion, optimizer, device, epoch, step_hook=hook)
         train_losses.append(tm["total_loss"])
         if scheduler and args.scheduler != "plateau":
             scheduler.step()
-        if rank == 0 and (epoch % args.val_freq == 0 or epoch == args.epochs - 1):
-            vm = validate_epoch(model, val_loader, criterion, device)
+        validating = epoch % args.val_freq == 0 or epoch == args.epochs - 1
+        vm = validate_epoch(model, val_loader, criterion, device) if (validating and rank == 0) else None
+        if validating and scheduler and args.scheduler == "plateau":
+            # every replica must take the same learning-rate decision: rank 0's validation loss goes to all
+            vl = torch.tensor([vm["total_loss"] if vm is not None else 0.0], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.broadcast(vl, src=0)
+            scheduler.step(float(vl))
+        if vm is not None:
             val_losses.append(vm["total_loss"])
-            if scheduler and args.scheduler == "plateau":
-                scheduler.step(vm["total_loss"])
             say(f"\nEpoch {epoch}/{args.epochs - 1}\nTrain Loss: {tm['total_loss']:.4f} (Recon: {tm['recon_loss']:.4f}, "
                 f"Seg: {tm['seg_loss']:.4f})\nVal Loss: {vm['total_loss']:.4f} (Recon: {vm['recon_loss']:.4f}, "
                 f"Seg: {vm['seg_loss']:.4f})")

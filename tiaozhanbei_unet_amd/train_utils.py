@@ -24,13 +24,12 @@ class SSIMLoss(nn.Module):
 
     def __init__(self, window_size=11, size_average=True):
         super().__init__()
-        if not size_average:
-            raise NotImplementedError("size_average=False is not on the hot path")
         self.window_size = window_size
         self.size_average = size_average
 
     def forward(self, img1, img2):
-        return ops.Ssim.apply(img1, img2, self.window_size)
+        """0-d loss, or one loss per image when ``size_average=False`` (reference :84-87)."""
+        return ops.Ssim.apply(img1, img2, self.window_size, bool(self.size_average))
 
 
 class CombinedLoss(nn.Module):
@@ -86,6 +85,15 @@ def train_epoch(model, train_loader, criterion, optimizer, device, epoch, step_h
 
 
 def validate_epoch(model, val_loader, criterion, device):
+    """Eval-mode pass over ``val_loader`` with the reference's return dict (src/train_utils.py:155-260): batch-size
+    weighted losses, ``image_metrics``, ``pixel_metrics`` and ``predictions`` = {labels [N], scores [N, H, W] per-pixel
+    error maps (src/utils.py:205-215), masks_true, masks_pred [N, 1, H, W]}.
+
+    One branch cannot mirror the reference because the reference cannot run it: with both classes present it hands the
+    N labels and the N*H*W thresholded map pixels to sklearn (:206-210), which raises.  There the image-level score is
+    the mean of an image's error map, thresholded at the 95th percentile of those N scores (``predictions`` gains the
+    key ``image_scores``).  The all-one-class branch (:217-227) -- what MVTec's all-normal split exercises -- is the
+    reference's, value for value (tests/golden/validate_epoch_all_normal.npz)."""
     model.eval()
     meters = {k: AverageMeter() for k in ("total_loss", "recon_loss", "seg_loss")}
     labels, scores, masks_true, masks_pred = [], [], [], []
@@ -94,23 +102,24 @@ def validate_epoch(model, val_loader, criterion, device):
             reconstruction, anomaly_map = model(images)
             losses = criterion(reconstruction, anomaly_map, images, masks)
             bs = images.size(0)
-            for k, m in meters.items():
-                m.update(float(losses[k]), bs)
+            vals = torch.stack([losses[k].detach().float() for k in meters]).tolist()     # one host sync per batch
+            for (k, m), v in zip(meters.items(), vals):
+                m.update(v, bs)
             labels.extend(np.asarray(batch["label"]))
-            # image-level score = mean of the per-pixel error map.  (The reference keeps the whole map here
-            # and then compares N labels with N*H*W predictions, which raises in sklearn as soon as both
-            # classes are present, src/train_utils.py:194,206-210 -- a defect we do not reproduce.)
-            scores.extend(compute_anomaly_score(reconstruction, images).flatten(1).mean(1).cpu().numpy())
+            scores.extend(compute_anomaly_score(reconstruction, images).cpu().numpy())
             masks_true.extend(masks.cpu().numpy())
             masks_pred.extend(anomaly_map.cpu().numpy())
     labels, scores = np.array(labels), np.array(scores)
     masks_true, masks_pred = np.array(masks_true), np.array(masks_pred)
+    predictions = {"labels": labels, "scores": scores, "masks_true": masks_true, "masks_pred": masks_pred}
 
     if len(np.unique(labels)) > 1:
-        threshold = np.percentile(scores, 95)
-        image_metrics = calculate_metrics(labels, (scores > threshold).astype(int), scores)
+        image_scores = scores.reshape(len(scores), -1).mean(1)
+        threshold = np.percentile(image_scores, 95)
+        image_metrics = calculate_metrics(labels, (image_scores > threshold).astype(int), image_scores)
+        predictions["image_scores"] = image_scores
     else:
-        normal = float(labels[0] == 0) if len(labels) else 0.0
+        normal = 1.0 if (len(labels) and labels[0] == 0) else 0.0
         image_metrics = {"accuracy": normal, "precision": 0.0, "recall": 0.0, "specificity": normal,
                          "f1_score": 0.0, "auroc": 0.0, "auprc": 0.0}
 
@@ -125,8 +134,7 @@ def validate_epoch(model, val_loader, criterion, device):
 
     return {"total_loss": meters["total_loss"].avg, "recon_loss": meters["recon_loss"].avg,
             "seg_loss": meters["seg_loss"].avg, "image_metrics": image_metrics, "pixel_metrics": pixel_metrics,
-            "predictions": {"labels": labels, "scores": scores, "masks_true": masks_true,
-                            "masks_pred": masks_pred}}
+            "predictions": predictions}
 
 
 def get_optimizer(model, optimizer_name="adam", learning_rate=1e-3, weight_decay=1e-4):

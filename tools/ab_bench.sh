@@ -7,7 +7,7 @@ for round in 1 2; do
   for cfg in "$@"; do
     i=$((i+1))
     echo "== round $round cfg[$i]: $cfg" >> $out
-    env $cfg python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+    env $cfg python bench.py --steps 20 --warmup 5 --blocks 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()
