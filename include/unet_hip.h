@@ -319,6 +319,13 @@ size_t unet_anomaly_score_workspace(int32_t n, int64_t hw);
 int32_t unet_anomaly_score(const float* recon, const float* image, int32_t n, int32_t c, int64_t hw, int32_t l1,
                            float* score, float* image_score, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- input pipeline on the GPU: transforms.ToTensor() + Normalize(mean, std) (+ the training
+ * RandomHorizontalFlip) of src/dataset.py:134-146 / src/kolektorsdd_dataset.py:133-150 for a batch of decoded uint8
+ * images [n][h][w][3] (device memory): out[n][c][y][x] = (u8 / 255 - mean[c]) / std[c], mirrored in x where flip[n] != 0
+ * (flip may be NULL; mean3 / std3 are HOST arrays).  The same fp32 operations in the same order: bit-identical. */
+int32_t unet_preprocess_u8(const uint8_t* images_hwc, const uint8_t* flip, float* out_nchw, int32_t n, int32_t h,
+                           int32_t w, const float* mean3, const float* std3, void* stream);
+
 /* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
  * gradient pre-scale (1/world_size under data parallelism). step is 1-based. */
 int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

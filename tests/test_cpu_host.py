@@ -125,3 +125,38 @@ def test_shard_sampler_gives_disjoint_equal_shards():
         if n > world:
             assert list(iter(s0)) != shards[0]
     assert list(iter(ShardSampler(5, 1, 2, shuffle=False))) == [1, 3, 0]
+
+
+def test_kolektorsdd_reader_contract(tmp_path):
+    """kolektorsdd_dataset.KolektorSDDDataset against the reference's rules (src/kolektorsdd_dataset.py:47-126):
+    sorted discovery of kos*/X.jpg + X_label.bmp pairs, 70/15/15 split sizes from the sorted list then the seed-42
+    shuffle (identical to `random.seed(42); random.shuffle(...)`), masks clamped to {0,1,2} and resized NEAREST,
+    (image, mask, path) samples, 3 classes.  (torchvision is not importable here: parity with the reference's
+    transforms is pinned by rule, not by fixture -- "parity unpinned" for the PIL resize.)"""
+    import random
+    import numpy as np
+    import torch
+    from tiaozhanbei_unet_amd import kolektorsdd_dataset as K
+    root = K.write_synthetic_kolektorsdd(str(tmp_path / "kol"), n_folders=5, per_folder=4, size=(160, 64))
+    pairs = K.list_samples(root)
+    assert len(pairs) == 20 and pairs == sorted(pairs) and all(m.endswith("_label.bmp") for _, m in pairs)
+    ref = list(pairs)
+    random.seed(42)
+    random.shuffle(ref)                                       # what the reference does (:79-80)
+    got = {s: K.split_samples(pairs, s) for s in ("train", "val", "test")}
+    assert got["train"] == ref[:14] and got["val"] == ref[14:17] and got["test"] == ref[17:]
+    ds = K.KolektorSDDDataset(root, "train", image_size=(96, 32))
+    img, mask, path = ds[0]
+    assert img.shape == (3, 96, 32) and img.dtype == torch.float32 and mask.shape == (96, 32) and mask.dtype == torch.int64
+    assert int(mask.max()) <= 2 and int(mask.min()) >= 0 and os.path.exists(path) and ds.num_classes == 3
+    raw = K.KolektorSDDDataset(root, "train", image_size=(96, 32), raw=True)
+    u8, mask2, _ = raw[0]
+    assert u8.dtype == torch.uint8 and u8.shape == (96, 32, 3) and torch.equal(mask, mask2)
+    want = (u8.float().permute(2, 0, 1) / 255.0 - torch.tensor(K.MEAN)) / torch.tensor(K.STD)
+    assert torch.equal(img, want)
+    tr, va, te, ncls = K.get_kolektorsdd_dataloaders(root, batch_size=4, image_size=(96, 32), num_workers=0)
+    assert ncls == 3 and len(tr.dataset) == 14 and len(va.dataset) == 3 and len(te.dataset) == 3
+    xb, mb, pb = next(iter(va))
+    assert xb.shape == (3, 3, 96, 32) and mb.shape == (3, 96, 32) and len(pb) == 3
+    tr2, _, _, _ = K.get_kolektorsdd_dataloaders(root, batch_size=2, image_size=(96, 32), num_workers=0, rank=1, world=2)
+    assert len(tr2.sampler) == 7

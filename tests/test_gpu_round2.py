@@ -316,3 +316,18 @@ def test_data_parallel_gradients_equal_mean_of_shard_gradients(tmp_path):
     assert worst < 1e-5, f"worst relative gradient difference {worst:.3e}"
     assert got["ranks_equal"], "the two ranks hold different reduced gradients"
     assert len(got["bucket_mb"]) >= 3
+
+
+def test_gpu_preprocess_is_bit_identical_to_host_transform():
+    """unet_preprocess_u8 (ToTensor + Normalize + optional horizontal flip on the GPU, reference src/dataset.py:134-146)
+    against the same fp32 arithmetic on the host: bit-identical."""
+    from tiaozhanbei_unet_amd import ops
+    from tiaozhanbei_unet_amd.dataset import MEAN, STD
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (3, 37, 52, 3), generator=g, dtype=torch.uint8)
+    flips = torch.tensor([False, True, False])
+    out = ops.preprocess_u8(u8.to(DEV), flips.to(DEV)).cpu()
+    want = (u8.float().permute(0, 3, 1, 2) / 255.0 - torch.tensor(MEAN)) / torch.tensor(STD)
+    want[1] = want[1].flip(-1)
+    assert out.shape == (3, 3, 37, 52) and torch.equal(out, want)
+    assert torch.equal(ops.preprocess_u8(u8.to(DEV)).cpu()[1], want[1].flip(-1))

@@ -579,3 +579,39 @@ extern "C" int32_t unet_adam_step(float* param, const float* grad, float* exp_av
                      (float)sqrt(bc2));
   return unet_check_launch("adam_kernel");
 }
+
+// ---- ToTensor + Normalize (+ horizontal flip) of uint8 HWC image batches (src/dataset.py:134-146,
+// src/kolektorsdd_dataset.py:133-150): out[n][c][y][x] = (u8[n][y][x'][c] / 255 - mean[c]) / std[c], x' = W-1-x when
+// flip[n].  The same fp32 operations in the same order as torchvision's ToTensor().div(255) and Normalize.sub_().div_():
+// bit-identical to the host transform.
+namespace {
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ src,
+                                                            const unsigned char* __restrict__ flip,
+                                                            float* __restrict__ dst, int N, int H, int W,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long total = (long long)N * H * W;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long long r = i / W;
+    const int y = (int)(r % H), n = (int)(r / H);
+    const int xs = (flip && flip[n]) ? W - 1 - x : x;
+    const unsigned char* p = src + (((long long)n * H + y) * W + xs) * 3;
+    const long long plane = (long long)H * W;
+    float* o = dst + (long long)n * 3 * plane + (long long)y * W + x;
+    o[0] = ((float)p[0] / 255.f - m0) / s0;
+    o[plane] = ((float)p[1] / 255.f - m1) / s1;
+    o[2 * plane] = ((float)p[2] / 255.f - m2) / s2;
+  }
+}
+}  // namespace
+
+extern "C" int32_t unet_preprocess_u8(const uint8_t* images_hwc, const uint8_t* flip, float* out_nchw, int32_t n, int32_t h,
+                                      int32_t w, const float* mean3, const float* std3, void* stream) {
+  UNET_REQUIRE(images_hwc && out_nchw && mean3 && std3, UNET_ERR_BAD_ARG, "unet_preprocess_u8: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_preprocess_u8: bad dims");
+  const long long total = (long long)n * h * w;
+  const int blocks = (int)std::min<long long>(cdiv64(total, 256), 256 * 16);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, images_hwc, flip, out_nchw, n, h, w,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return unet_check_launch("preprocess_u8_kernel");
+}

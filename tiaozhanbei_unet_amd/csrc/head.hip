@@ -287,6 +287,205 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// head_bwd_tile_kernel: the backward of the 64-input-channel head, re-laid so that a lane's state is a handful of
+// registers (the kernel above keeps 8 channels x (CO filters + CO weight-gradient sums + 5 BatchNorm values) per lane:
+// 200-256 VGPRs, one wave per SIMD, 2.8 TB/s).  A wave takes a tile of 64 consecutive pixels x 64 channels:
+//   1. the tile of x (or of the raw conv output y when BN) travels global -> LDS as eight fully coalesced 1-KiB
+//      wave loads; lane = pixel reads the NCHW fp32 planes (out, dout) coalesced and leaves dlogit[co][pixel] in LDS;
+//   2. lane = (channel pair, pixel parity) walks the tile's 32 pixels of its parity: reads its two channels of a
+//      pixel (one 4-byte LDS read: conflict-free, a row is 128 B), the pixel's CO dlogits (LDS broadcast), forms the
+//      activation, dx (with the ReLU mask when BN), the weight-gradient and BatchNorm-backward sums of ITS two
+//      channels (2*CO + 4 accumulators) and writes dx back over the tile in place;
+//   3. the tile goes LDS -> global with eight coalesced 16-byte stores per lane.
+// ~50 VGPRs, 33 KB LDS per block: four blocks per CU keep the memory pipes full.  Same outputs and partial-sum
+// formats as head_bwd_kernel (the finalize kernels are shared).
+template <typename T, int CO, bool BN>
+__global__ __launch_bounds__(256) void head_bwd_tile_kernel(const T* __restrict__ x, const float* __restrict__ out,
+                                                            const float* __restrict__ dout, long long pixels,
+                                                            long long hw, const float* __restrict__ w, int sigm,
+                                                            T* __restrict__ dx, float* __restrict__ part,
+                                                            const float* __restrict__ bn_scale,
+                                                            const float* __restrict__ bn_shift,
+                                                            const float* __restrict__ bn_mean,
+                                                            float* __restrict__ bn_part) {
+  constexpr int CIN = 64, ES = ET<T>::ES;
+  constexpr int ROW = CIN * ES;                       // bytes per pixel row
+  constexpr int TILE = 64 * ROW;                      // 8 KiB (bf16) / 16 KiB (fp32) per wave
+  constexpr int NLD = TILE / 1024;                    // 16-byte pieces per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* const tile = smem + wave * (TILE + CO * 256);
+  float* const dlt = reinterpret_cast<float*>(tile + TILE);           // [CO][64]
+  const int c2 = lane & 31, ph = lane >> 5;           // pixels of parity ph; this lane's two channels:
+  // bf16: 2*c2, 2*c2+1 (one packed 4-byte LDS access); fp32: c2, c2+32 (two 4-byte accesses, each conflict-free --
+  // an 8-byte vector access here is split and mis-merged across the unrolled iterations by hipcc 7.2's LDS load combiner)
+  const int ch0 = sizeof(T) == 2 ? 2 * c2 : c2, ch1 = sizeof(T) == 2 ? 2 * c2 + 1 : c2 + 32;
+  float wr[CO][2], dwacc[CO][2], dbacc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    wr[co][0] = w[co * CIN + ch0]; wr[co][1] = w[co * CIN + ch1];
+    dwacc[co][0] = dwacc[co][1] = 0.f; dbacc[co] = 0.f;
+  }
+  float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f}, mu[2] = {0.f, 0.f}, bs0[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = j ? ch1 : ch0;
+      sc[j] = bn_scale[ch]; sh[j] = bn_shift[ch]; mu[j] = bn_mean[ch];
+    }
+  }
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long c = blockIdx.x * 4LL + wave; c * 64 < pixels; c += nw) {
+    const long long base = c * 64;
+    // ---- 1. tile -> LDS (contiguous in NHWC), dlogits -> LDS
+    u32x4 ld[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = i * 64 + lane;                    // 16-byte piece index inside the tile
+      const long long p = base + q / (ROW / 16);
+      ld[i] = u32x4{0u, 0u, 0u, 0u};
+      if (p < pixels) ld[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + base * ROW + (size_t)q * 16);
+    }
+    {
+      const long long p = base + lane;
+      float dl[CO];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) dl[co] = 0.f;
+      if (p < pixels) {
+        long long n, q;
+        split_pixel(p, hw, n, q);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          float d = dout[(n * CO + co) * hw + q];
+          if (sigm) { const float o = out[(n * CO + co) * hw + q]; d *= o * (1.f - o); }
+          dl[co] = d;
+          dbacc[co] += d;
+        }
+      }
+#pragma unroll
+      for (int co = 0; co < CO; ++co) dlt[co * 64 + lane] = dl[co];
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(tile + (i * 64 + lane) * 16) = ld[i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS writes are done (one wave owns a tile)
+    // ---- 2. lane = (channel pair, pixel parity)
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+      const int p = 2 * k + ph;
+      float v[2];
+      if constexpr (sizeof(T) == 2) {
+        const unsigned u = *reinterpret_cast<const unsigned*>(tile + p * ROW + c2 * 4);
+        v[0] = __builtin_bit_cast(float, u << 16);
+        v[1] = __builtin_bit_cast(float, u & 0xFFFF0000u);
+      } else {
+        v[0] = *reinterpret_cast<const float*>(tile + p * ROW + ch0 * 4);
+        v[1] = *reinterpret_cast<const float*>(tile + p * ROW + ch1 * 4);
+      }
+      float ds[CO];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) ds[co] = dlt[co * 64 + p];
+      float d[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float av = v[j];
+        bool on = true;
+        if constexpr (BN) {
+          const float z = fmaf(v[j], sc[j], sh[j]);
+          on = z > 0.f;
+          av = ET<T>::to_f(ET<T>::from_f(fmaxf(z, 0.f)));       // the activation the 1x1 filter saw
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          t = fmaf(ds[co], wr[co][j], t);
+          dwacc[co][j] = fmaf(ds[co], av, dwacc[co][j]);        // a pixel past the end has ds = 0
+        }
+        if constexpr (BN) {
+          t = ET<T>::to_f(ET<T>::from_f(on ? t : 0.f));         // dz as stored
+          bs0[j] += t;
+          bs1[j] = fmaf(t, v[j] - mu[j], bs1[j]);
+        }
+        d[j] = t;
+      }
+      if constexpr (sizeof(T) == 2) {
+        const bf16_t d0 = (bf16_t)d[0], d1 = (bf16_t)d[1];
+        const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, d0) | ((unsigned)__builtin_bit_cast(unsigned short, d1) << 16);
+        *reinterpret_cast<unsigned*>(tile + p * ROW + c2 * 4) = u;
+      } else {
+        *reinterpret_cast<float*>(tile + p * ROW + ch0 * 4) = d[0];
+        *reinterpret_cast<float*>(tile + p * ROW + ch1 * 4) = d[1];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- 3. tile -> global
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = i * 64 + lane;
+      const long long p = base + q / (ROW / 16);
+      const u32x4 r = *reinterpret_cast<const u32x4*>(tile + q * 16);
+      if (p < pixels) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dx) + base * ROW + (size_t)q * 16) = r;
+    }
+    __builtin_amdgcn_wave_barrier();                 // (the next tile's LDS writes must not pass these reads)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // ---- block partials.  dW / BatchNorm sums: the two parity halves hold the same channels; db: lane = pixel partials
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dwacc[co][j] += __shfl_xor(dwacc[co][j], 32);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) dbacc[co] += __shfl_xor(dbacc[co], m);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { bs0[j] += __shfl_xor(bs0[j], 32); bs1[j] += __shfl_xor(bs1[j], 32); }
+  __syncthreads();                                   // every wave is done with its tile area
+  float* red = reinterpret_cast<float*>(smem);       // [4 waves][CO * 65 + 128]
+  constexpr int stride = CIN + 1, RW = CO * stride + 2 * CIN;
+  if (ph == 0) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      red[wave * RW + co * stride + ch0] = dwacc[co][0];
+      red[wave * RW + co * stride + ch1] = dwacc[co][1];
+      if (lane == 0) red[wave * RW + co * stride + CIN] = dbacc[co];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      red[wave * RW + CO * stride + (j ? ch1 : ch0)] = bs0[j];
+      red[wave * RW + CO * stride + CIN + (j ? ch1 : ch0)] = bs1[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CO * stride; i += 256)
+    part[(size_t)blockIdx.x * CO * stride + i] = (red[i] + red[RW + i]) + (red[2 * RW + i] + red[3 * RW + i]);
+  if constexpr (BN) {
+    for (int i = threadIdx.x; i < 2 * CIN; i += 256) {
+      const int o = CO * stride + i;
+      bn_part[(size_t)blockIdx.x * 2 * CIN + i] = (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]);
+    }
+  }
+}
+
+template <typename T, int CO, bool BN>
+int32_t launch_head_bwd_tile(const void* x, const float* out, const float* dout, long long pixels, long long hw,
+                             const float* w, int sigm, void* dx, float* part, const float* bn_scale,
+                             const float* bn_shift, const float* bn_mean, float* bn_part, int nb, hipStream_t s) {
+  constexpr int TILE = 64 * 64 * ET<T>::ES;
+  constexpr int LDS = 4 * (TILE + CO * 256);
+  static_assert(LDS >= 4 * (CO * 65 + 128) * 4, "reduction scratch fits the tile area");
+  auto kern = head_bwd_tile_kernel<T, CO, BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(256), LDS, s, (const T*)x, out, dout, pixels, hw, w, sigm, (T*)dx, part,
+                     bn_scale, bn_shift, bn_mean, bn_part);
+  return unet_check_launch("head_bwd_tile_kernel");
+}
+
 inline int head_blocks(long long pixels, int tpp) {
   (void)tpp;
   long long b = cdiv64(pixels, 256 * 4);         // a wave takes 64 pixels per iteration, ~4 iterations per wave
@@ -362,7 +561,18 @@ extern "C" int32_t unet_head_bwd(int32_t dtype, const void* x, const float* out,
   const long long pixels = (long long)n * h * w, hw = (long long)h * w;
   ProfScope prof(UNET_K_HEAD, 4.0 * pixels * c_in * c_out, s);
   int nb = 0;
-  if (dtype == UNET_BF16) {
+  if (c_in == 64 && (dtype == UNET_BF16 || dtype == UNET_F32)) {
+    nb = head_blocks(pixels, 8);
+    int32_t rc = UNET_OK;
+    if (dtype == UNET_BF16) {
+      HEAD_CO_SWITCH(rc = (launch_head_bwd_tile<bf16_t, CO, false>(x, out, dout, pixels, hw, weight, sigmoid, dx, (float*)workspace,
+                                                                 nullptr, nullptr, nullptr, nullptr, nb, s)));
+    } else {
+      HEAD_CO_SWITCH(rc = (launch_head_bwd_tile<float, CO, false>(x, out, dout, pixels, hw, weight, sigmoid, dx, (float*)workspace,
+                                                                nullptr, nullptr, nullptr, nullptr, nb, s)));
+    }
+    if (rc) return rc;
+  } else if (dtype == UNET_BF16) {
     const int tpp = tpp_of<bf16_t>(c_in);
     nb = head_blocks(pixels, tpp);
     HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP, CO>), dim3(nb), dim3(256), 0, s,
@@ -426,7 +636,18 @@ extern "C" int32_t unet_head_bnrelu_bwd(int32_t dtype, const void* y, const floa
   const long long pixels = (long long)n * h * w, hw = (long long)h * w;
   ProfScope prof(UNET_K_HEAD, 4.0 * pixels * c_in * c_out, s);
   int nb = 0;
-  if (dtype == UNET_BF16) {
+  if (c_in == 64 && (dtype == UNET_BF16 || dtype == UNET_F32)) {
+    nb = head_blocks(pixels, 8);
+    int32_t rc = UNET_OK;
+    if (dtype == UNET_BF16) {
+      HEAD_CO_SWITCH(rc = (launch_head_bwd_tile<bf16_t, CO, true>(y, out, dout, pixels, hw, weight, sigmoid, dz, (float*)workspace,
+                                                                bn_scale, bn_shift, bn_mean, bn_partial, nb, s)));
+    } else {
+      HEAD_CO_SWITCH(rc = (launch_head_bwd_tile<float, CO, true>(y, out, dout, pixels, hw, weight, sigmoid, dz, (float*)workspace,
+                                                               bn_scale, bn_shift, bn_mean, bn_partial, nb, s)));
+    }
+    if (rc) return rc;
+  } else if (dtype == UNET_BF16) {
     const int tpp = tpp_of<bf16_t>(c_in);
     nb = head_blocks(pixels, tpp);
     HEAD_TPP_SWITCH(bf16_t, tpp, hipLaunchKernelGGL((head_bwd_kernel<bf16_t, TPP, CO, true>), dim3(nb), dim3(256), 0, s,

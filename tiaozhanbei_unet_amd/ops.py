@@ -885,6 +885,25 @@ class Ssim(torch.autograd.Function):
         return d1 * g, d2 * g, None, None
 
 
+def preprocess_u8(images_u8, flips=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """uint8 [N, H, W, 3] device batch -> normalised fp32 NCHW (ToTensor + Normalize, optional per-sample horizontal
+    flip): /root/reference/src/dataset.py:134-146, src/kolektorsdd_dataset.py:133-150, on the GPU."""
+    _require_cuda(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
+        raise ValueError("preprocess_u8 expects a uint8 [N, H, W, 3] tensor")
+    images_u8 = images_u8.contiguous()
+    n, h, w, _ = images_u8.shape
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=images_u8.device)
+    fl = None
+    if flips is not None:
+        fl = flips.to(device=images_u8.device, dtype=torch.uint8).contiguous()
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s_ = (C.c_float * 3)(*[float(v) for v in std])
+    L.check(L.lib().unet_preprocess_u8(_ptr(images_u8), _ptr(fl), _ptr(out), n, h, w, m, s_, _stream()),
+            "unet_preprocess_u8")
+    return out
+
+
 # ----------------------------------------------------------------------------- profiling / optimiser
 def prof_enable(on: bool) -> None:
     L.check(L.lib().unet_prof_enable(int(on)), "unet_prof_enable")
