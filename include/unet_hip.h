@@ -332,6 +332,28 @@ int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* e
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        float grad_scale, int32_t step, void* stream);
 
+/* The optimiser step of get_optimizer's Adam / AdamW (src/train_utils.py:263-270) for ALL parameter tensors of a model in
+ * ONE launch (the reference's torch.optim.Adam walks the 98 tensors): descs (DEVICE array) = one entry per tensor,
+ * chunks (DEVICE array) = one entry per block: block b updates elements [first, first + unet_adam_chunk_elems()) of
+ * tensor `tensor`.  Same arithmetic as unet_adam_step; decoupled != 0 = AdamW (p *= 1 - lr*wd instead of g += wd*p);
+ * grad_scale folds the 1/world of data parallelism into the step. */
+typedef struct unet_adam_desc {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} unet_adam_desc;
+typedef struct unet_adam_chunk {
+  int32_t tensor;
+  int32_t reserved;
+  int64_t first;
+} unet_adam_chunk;
+int32_t unet_adam_chunk_elems(void);
+int32_t unet_adam_multi(const unet_adam_desc* descs, const unet_adam_chunk* chunks, int32_t n_chunks, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, int32_t step, int32_t decoupled,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,3 +331,45 @@ def test_gpu_preprocess_is_bit_identical_to_host_transform():
     want[1] = want[1].flip(-1)
     assert out.shape == (3, 3, 37, 52) and torch.equal(out, want)
     assert torch.equal(ops.preprocess_u8(u8.to(DEV)).cpu()[1], want[1].flip(-1))
+
+
+@pytest.mark.parametrize("decoupled", [False, True], ids=["adam", "adamw"])
+def test_fused_multi_tensor_adam_matches_torch(decoupled):
+    """optim.FusedAdam (one unet_adam_multi launch for all tensors) against torch.optim.Adam / AdamW on tensors of
+    awkward sizes (scalar tails, several chunks), 4 steps with changing gradients; state_dicts are interchangeable;
+    grad_scale folds a 1/world factor."""
+    from tiaozhanbei_unet_amd.optim import FusedAdam
+    torch.manual_seed(1)
+    shapes = [(1,), (3,), (64, 3, 3, 3), (4097,), (2, 4096), (129, 64, 3, 3)]
+    ref_p = [torch.randn(s).requires_grad_(True) for s in shapes]
+    got_p = [p.detach().clone().to(DEV).requires_grad_(True) for p in ref_p]
+    kw = dict(lr=3e-3, weight_decay=1e-2)
+    ref = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref_p, **kw)
+    got = FusedAdam(got_p, decoupled=decoupled, **kw)
+    got.grad_scale = 0.5
+    for step in range(4):
+        for r, g in zip(ref_p, got_p):
+            grad = torch.randn(r.shape) * (1.0 + step)
+            r.grad = grad.clone()
+            g.grad = (grad * 2.0).to(DEV)                    # the kernel scales it back by grad_scale = 0.5
+        ref.step()
+        got.step()
+    for r, g in zip(ref_p, got_p):
+        assert maxabs(g, r) <= 2e-6 * max(1.0, float(r.abs().max())), (tuple(r.shape), maxabs(g, r))
+    sd = got.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+    assert maxabs(sd["state"][5]["exp_avg_sq"], ref.state_dict()["state"][5]["exp_avg_sq"]) < 1e-6
+    # a torch optimiser takes the fused one's state and continues identically (checkpoint interchange)
+    ref2_p = [p.detach().clone().cpu().requires_grad_(True) for p in got_p]
+    ref2 = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref2_p, **kw)
+    ref2.load_state_dict({"state": {k: {n: (t.cpu() if torch.is_tensor(t) else t) for n, t in v.items()}
+                                    for k, v in sd["state"].items()},
+                          "param_groups": [{k: v for k, v in ref2.state_dict()["param_groups"][0].items()}]})
+    got.grad_scale = 1.0
+    for r, g in zip(ref2_p, got_p):
+        grad = torch.randn(r.shape)
+        r.grad, g.grad = grad.clone(), grad.to(DEV)
+    ref2.step()
+    got.step()
+    for r, g in zip(ref2_p, got_p):
+        assert maxabs(g, r) <= 2e-6 * max(1.0, float(r.abs().max()))

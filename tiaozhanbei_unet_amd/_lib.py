@@ -90,6 +90,8 @@ SIGNATURES = {
     "unet_anomaly_score_workspace": (_z, [_i, _l]),
     "unet_anomaly_score": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p, _z, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "unet_adam_chunk_elems": (_i, []),
+    "unet_adam_multi": (_i, [_p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
     "unet_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _i, _p]),
 }
 

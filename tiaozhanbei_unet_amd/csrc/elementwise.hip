@@ -564,6 +564,65 @@ extern "C" int32_t unet_anomaly_score(const float* recon, const float* image, in
   return unet_check_launch("anomaly_score_finalize_kernel");
 }
 
+// All parameter tensors of a model in ONE launch: descs[t] = {p, g, m, v, n}; chunks[b] = {tensor, first element}: block b
+// updates up to ADAM_CHUNK elements of its tensor (vector path on the 16-byte-aligned body, scalar tail).
+namespace {
+constexpr int ADAM_CHUNK = 4096;
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float b1, float b2, float eps,
+                                         float wd, float gscale, float bc2_sqrt, int decoupled) {
+  float gr = g * gscale;
+  if (!decoupled) gr = fmaf(wd, p, gr);               // Adam: the L2 term joins the gradient (torch.optim.Adam)
+  m = b1 * m + (1.f - b1) * gr;
+  v = b2 * v + (1.f - b2) * gr * gr;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p -= lr_bc1 * (m / denom);
+}
+__global__ __launch_bounds__(256) void adam_multi_kernel(const unet_adam_desc* __restrict__ descs,
+                                                         const unet_adam_chunk* __restrict__ chunks, float lr, float b1,
+                                                         float b2, float eps, float wd, float gscale, float bc1,
+                                                         float bc2_sqrt, int decoupled) {
+  const unet_adam_chunk ck = chunks[blockIdx.x];
+  const unet_adam_desc d = descs[ck.tensor];
+  const long long begin = ck.first, end = begin + ADAM_CHUNK < d.n ? begin + ADAM_CHUNK : d.n;
+  const float lr_bc1 = lr / bc1;
+  const float decay = decoupled ? 1.f - lr * wd : 1.f;             // AdamW: p *= 1 - lr*wd before the update
+  const long long vend = begin + ((end - begin) / 4) * 4;
+  for (long long i = begin + threadIdx.x * 4LL; i < vend; i += 1024) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(d.p + i), gg = *reinterpret_cast<const f32x4*>(d.g + i);
+    f32x4 mm = *reinterpret_cast<f32x4*>(d.m + i), vv = *reinterpret_cast<f32x4*>(d.v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pj = pp[j] * decay, mj = mm[j], vj = vv[j];
+      adam_one(pj, gg[j], mj, vj, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt, decoupled);
+      pp[j] = pj; mm[j] = mj; vv[j] = vj;
+    }
+    *reinterpret_cast<f32x4*>(d.p + i) = pp;
+    *reinterpret_cast<f32x4*>(d.m + i) = mm;
+    *reinterpret_cast<f32x4*>(d.v + i) = vv;
+  }
+  for (long long i = vend + threadIdx.x; i < end; i += 256) {
+    float pp = d.p[i] * decay, mm = d.m[i], vv = d.v[i];
+    adam_one(pp, d.g[i], mm, vv, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt, decoupled);
+    d.p[i] = pp; d.m[i] = mm; d.v[i] = vv;
+  }
+}
+}  // namespace
+
+extern "C" int32_t unet_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+extern "C" int32_t unet_adam_multi(const unet_adam_desc* descs, const unet_adam_chunk* chunks, int32_t n_chunks, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step,
+                                   int32_t decoupled, void* stream) {
+  UNET_REQUIRE(descs && chunks && n_chunks > 0 && step >= 1, UNET_ERR_BAD_ARG, "unet_adam_multi: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_OTHER, 0.0, s, "adam_multi_kernel");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, descs, chunks, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2), decoupled);
+  return unet_check_launch("adam_multi_kernel");
+}
+
 extern "C" int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay,
                                   float grad_scale, int32_t step, void* stream) {

@@ -1411,14 +1411,24 @@ struct CfgWS {
   static constexpr int NDMA = (NINSTR + NWAVE - 1) / NWAVE;     // per wave per tile (surplus ones hit a dummy KiB)
   static constexpr int A_BYTES = NINSTR * 1024;
   static constexpr int NBUF = 3;                                // patch ring: 2 tiles in flight behind the one computing
-  static constexpr int LDS = NBUF * A_BYTES + 1024;             // + dummy target of the surplus (all-OOB) DMAs
+  static constexpr int RED_BASE = NBUF * A_BYTES + 1024;        // (+ dummy target of the surplus (all-OOB) DMAs)
+  static constexpr int RED_BYTES = 2 * 2 * 8 * 64 * 4;          // [2 tiles][2 statistics][8 half-wave slots][64 channels]
+  static constexpr int CT_BASE = RED_BASE + RED_BYTES;          // BatchNorm coefficients of the fused backward mask
+  static constexpr int LDS = CT_BASE + 3 * 64 * 4;
   static constexpr int PXT = 2;                                 // 64 pixels per wave
   static constexpr int ROWS = 64;                               // output channels per block
 };
 
-template <bool ACC>
+// STATS: 0 none; 1 = BatchNorm batch statistics of the stored outputs (sum, sum of squares: the forward of
+// conv -> BatchNorm, no separate pass over y); 2 = data gradient with the ReLU mask of the producing layer and its
+// BatchNorm-backward sums (sum dz, sum dz * (y - mean); see IgemmParams::bn_y).  A wave cannot afford per-lane running
+// sums next to its 144 weight registers, so every tile's 2 x 16 per-lane values are reduced over the 16 lanes of a DPP
+// row at once (4 VALU adds each), the four row leaders leave them in an LDS slot, and 128 threads keep the block's
+// running total of their (statistic, channel) -- one ordered partial per block: deterministic.
+template <bool ACC, int STATS = 0>
 __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, int tiles_per_block) {
   using C = CfgWS;
+  static_assert(!(ACC && STATS), "the gradient fan-in form carries no statistics");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave & 1, wpx = wave >> 1;
@@ -1433,7 +1443,18 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   const int total_tiles = P.N * tiles_img;
   const int t_begin = tr * tiles_per_block;
   const int t_end = min(t_begin + tiles_per_block, total_tiles);
-  if (t_begin >= t_end) return;
+  if (t_begin >= t_end) {
+    if (STATS && tid < 128)                       // an empty tile range still owns a partial: zeros
+      P.stats[((size_t)tr * 2 + (tid >> 6)) * P.Cout + cg * C::ROWS + (tid & 63)] = 0.f;
+    return;
+  }
+  float* const red = reinterpret_cast<float*>(smem + C::RED_BASE);
+  float* const ctab = reinterpret_cast<float*>(smem + C::CT_BASE);      // [scale | shift | mean][64]
+  if (STATS == 2 && tid < 192) {
+    const float* srcp = tid < 64 ? P.bn_scale : (tid < 128 ? P.bn_shift : P.bn_mean);
+    ctab[tid] = srcp[cg * C::ROWS + (tid & 63)];
+  }
+  float stat_tot = 0.f;
 
   // ---- this wave's weights -> registers: A fragment (tap, kg) = W[co_lane][tap][16*kg + 8*hh .. +7]
   bf16x8 wreg[36];
@@ -1495,8 +1516,12 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   // dropped by the range check), so the ops younger than tile j's DMAs are known exactly:
   //   stores(j-2) + DMA(j+1) + stores(j-1)  ->  vmcnt(2*NST + NDMA) retires tile j's patch while the next
   //   patch and 32 stores stay in flight.  Raw s_barrier (a __syncthreads() here would emit vmcnt(0)).
-  constexpr int NST = 2 * C::PXT * 2;            // stores per wave per tile: 2 sixteen-channel groups x PXT x 2 dst views
-  static_assert(2 * NST + C::NDMA <= 63, "vmcnt range");
+  constexpr int NVIEW = STATS ? 1 : 2;           // the statistics forms write ONE dense destination
+  constexpr int NST = 2 * C::PXT * NVIEW;        // stores per wave per tile: 2 sixteen-channel groups x PXT x dst views
+  // STATS == 2 adds NY loads of y per tile, issued BEFORE the tile's DMAs (so that waiting for them in the epilogue
+  // leaves those DMAs in flight); by the next tile's wait they are long complete but still count as issued-after
+  constexpr int NY = STATS == 2 ? 2 * C::PXT : 0;
+  static_assert(2 * NST + C::NDMA + NY <= 63, "vmcnt range");
 #pragma unroll
   for (int d = 0; d < C::NBUF - 1; ++d)
     if (t_begin + d < t_end) dma_a(t_begin + d, d);
@@ -1505,17 +1530,21 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     const int cur = k % C::NBUF;
     const bool next_in_flight = tile + 1 < t_end;
     if (k >= 2) {
-      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST + C::NDMA) : "memory");
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST + C::NDMA + NY) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
     } else if (k == 1) {
-      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + C::NDMA) : "memory");
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + C::NDMA + NY) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     } else {
       if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
+    if (STATS && k >= 1 && tid < 128) {            // the previous tile's slots -> this thread's running total
+      const float* rp = red + ((k - 1) & 1) * 1024 + (tid >> 6) * 512 + (tid & 63);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) stat_tot += rp[sl * 64];
+    }
 
     // ---- output geometry of this tile (buffer stores: an OOB offset = dropped, so the op count is static)
     const int n = tile / tiles_img, r = tile - n * tiles_img;
@@ -1531,7 +1560,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     // A lane of the 32x32 accumulator owns rows 8g+4hh..+3 of pixel l31; v_permlane32_swap trades the g-odd run
     // of the lower half-wave for the g-even run of the upper one, so every lane ends up with 8 CONSECUTIVE
     // channels (rows 16gp + 8hh ..+7) and writes 16 bytes: half as many store instructions, 32-byte segments.
-    unsigned ovo[C::PXT][2][2];
+    unsigned ovo[C::PXT][2][NVIEW];
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
       const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
@@ -1541,7 +1570,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       for (int gp = 0; gp < 2; ++gp) {
         const int co = cg * C::ROWS + wco * 32 + 16 * gp + 8 * hh;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                 // one store per destination view; the other one is OOB
+        for (int q = 0; q < NVIEW; ++q) {             // one store per destination view; the other one is OOB
           const DViewW D = P.dst[q];
           const int cq = q == 0 ? co : co - P.dst_split;
           const bool mine = (q == 0) == (co < P.dst_split);
@@ -1551,6 +1580,19 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
         }
       }
     }
+    // STATS == 2: this tile's y values (same offsets as the stores: dst[0] is dense and frame-sized) are requested
+    // FIRST, then the DMAs of the tile two ahead
+    u32x4 yv[STATS == 2 ? C::PXT : 1][2];
+    if constexpr (STATS == 2) {
+      const unsigned dimg = (unsigned)P.dst[0].H * P.dst[0].W * P.dst[0].C * 2u;
+      const __amdgpu_buffer_rsrc_t yrs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(P.bn_y + (size_t)n * dimg), (short)0, (int)dimg, 0x00020000);
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) yv[pt][gp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ovo[pt][gp][0], 0, 0);
+    }
+    if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
     // gradient fan-in (ACC): the old values are fetched NOW, behind the tile's 72 MFMAs (one load per output
     // run, from whichever view owns it and has its accumulate bit set; everything else reads as 0)
     u32x4 oldv[ACC ? C::PXT : 1][2];
@@ -1561,7 +1603,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
         for (int gp = 0; gp < 2; ++gp) {
           const bool second = ovo[pt][gp][0] == OOB;
           const bool want = (P.accumulate >> (second ? 1 : 0)) & 1;
-          const unsigned vo = want ? (second ? ovo[pt][gp][1] : ovo[pt][gp][0]) : OOB;
+          const unsigned vo = want ? (second ? ovo[pt][gp][NVIEW - 1] : ovo[pt][gp][0]) : OOB;
           oldv[pt][gp] = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
                                 : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
         }
@@ -1575,7 +1617,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     const char* pb = smem + cur * C::A_BYTES;
     // 36 (tap, 16-channel group) steps of PXT MFMAs; the pixel fragments of step i+2 are requested before the MFMAs
     // of step i and pinned there (left alone, hipcc requests them one MFMA ahead: the LDS round trip showed)
-    constexpr int DEPTH = 2;
+    constexpr int DEPTH = STATS == 2 ? 1 : 2;      // (the masked-gradient form needs the registers for its y values)
     auto frag = [&](int i, int pt) {
       const int tap = i >> 2, kg = i & 3;
       return *reinterpret_cast<const bf16x8*>(pb + boff[pt] + (tap / 3) * C::RS + (tap % 3) * C::PSTR + kg * 32);
@@ -1598,60 +1640,129 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped)
+    // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped).  Per 16-channel group gp
+    // the two 4-row runs of a lane (t = 0: rows 16gp+4hh.., t = 1: +8) are finished one after the other so that only
+    // one run's coefficients and sums are live (the statistics forms sit at the 256-register limit).
 #pragma unroll
-    for (int pt = 0; pt < C::PXT; ++pt) {
+    for (int gp = 0; gp < 2; ++gp) {
+      u32x2 pk[C::PXT][2];                         // packed bf16x4 results: [pixel tile][run]
+      u32x2 inp[C::PXT][2];                        // ACC: old values / STATS 2: y, in the accumulator's lane layout
+      if constexpr (ACC || STATS == 2) {
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        bf16x4 xa, xb;
-        if constexpr (ACC) {
-          // bring the old values (8 consecutive channels per lane) back to the accumulator's lane layout with the
-          // same exchange, add in fp32, round once
-          const u32x4 o = oldv[pt][gp];
+        for (int pt = 0; pt < C::PXT; ++pt) {
+          const u32x4 o = ACC ? oldv[pt][gp] : yv[pt][gp];
           const auto o0 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
           const auto o1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
-          const bf16x4 oa = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
-          const bf16x4 ob = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
+          inp[pt][0] = u32x2{o0[0], o1[0]};
+          inp[pt][1] = u32x2{o0[1], o1[1]};
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 csc, csh, cmu;
+        if constexpr (STATS == 2) {
+          const int cb = wco * 32 + 16 * gp + 4 * hh + 8 * t;
+          csc = *reinterpret_cast<const f32x4*>(ctab + cb);
+          csh = *reinterpret_cast<const f32x4*>(ctab + 64 + cb);
+          cmu = *reinterpret_cast<const f32x4*>(ctab + 128 + cb);
+        }
+#pragma unroll
+        for (int pt = 0; pt < C::PXT; ++pt) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = acc[pt][8 * gp + 4 * t + j];
+          bf16x4 x;
+          if constexpr (ACC) {
+            const bf16x4 o = __builtin_bit_cast(bf16x4, inp[pt][t]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (bf16_t)(f[j] + (float)o[j]);      // add in fp32, round once
+          } else if constexpr (STATS == 2) {
+            const bf16x4 yq = __builtin_bit_cast(bf16x4, inp[pt][t]);
+            const bool ok = ovo[pt][gp][0] != OOB;                                // a tile pixel outside the frame: no sums
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float yy = (float)yq[j];
+              x[j] = (bf16_t)((ok && fmaf(yy, csc[j], csh[j]) > 0.f) ? f[j] : 0.f);
+              const float q = (float)x[j];                                        // dz as stored
+              s0[j] += q;
+              s1[j] = fmaf(q, yy - cmu[j], s1[j]);
+            }
+          } else {
+            if (P.bias) {                            // inference: BatchNorm shift (+ ReLU) of the folded layer
+              const float* bp = P.bias + cg * C::ROWS + wco * 32 + 16 * gp + 4 * hh + 8 * t;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) f[j] += bp[j];
+            }
+            if (P.relu) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) f[j] = fmaxf(f[j], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (bf16_t)f[j];
+            if constexpr (STATS == 1) {
+              const bool ok = ovo[pt][gp][0] != OOB;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float q = ok ? (float)x[j] : 0.f;                           // the value as stored
+                s0[j] += q;
+                s1[j] = fmaf(q, q, s1[j]);
+              }
+            }
+          }
+          pk[pt][t] = __builtin_bit_cast(u32x2, x);
+        }
+        if constexpr (STATS != 0) {
+          float* rw = red + (k & 1) * 1024 + (wpx * 2 + ((lane >> 4) & 1)) * 64 + wco * 32 + 16 * gp + 4 * hh + 8 * t;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            xa[j] = (bf16_t)(acc[pt][8 * gp + j] + (float)oa[j]);
-            xb[j] = (bf16_t)(acc[pt][8 * gp + 4 + j] + (float)ob[j]);
+            const float t0 = row16_sum(s0[j]), t1 = row16_sum(s1[j]);
+            if ((lane & 15) == 0) { rw[j] = t0; rw[512 + j] = t1; }
           }
-        } else {
-          float fa4[4], fb4[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { fa4[j] = acc[pt][8 * gp + j]; fb4[j] = acc[pt][8 * gp + 4 + j]; }
-          if (P.bias) {                              // inference: BatchNorm shift (+ ReLU) of the folded layer
-            const float* bp = P.bias + cg * C::ROWS + wco * 32 + 16 * gp + 4 * hh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { fa4[j] += bp[j]; fb4[j] += bp[8 + j]; }
-          }
-          if (P.relu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { fa4[j] = fmaxf(fa4[j], 0.f); fb4[j] = fmaxf(fb4[j], 0.f); }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)fa4[j]; xb[j] = (bf16_t)fb4[j]; }
         }
-        const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
-        const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
-        const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][gp][q], 0, 0);
       }
+#pragma unroll
+      for (int pt = 0; pt < C::PXT; ++pt) {
+        const auto s0w = __builtin_amdgcn_permlane32_swap(pk[pt][0][0], pk[pt][1][0], false, false);
+        const auto s1w = __builtin_amdgcn_permlane32_swap(pk[pt][0][1], pk[pt][1][1], false, false);
+        const u32x4 bits = u32x4{s0w[0], s1w[0], s0w[1], s1w[1]};
+#pragma unroll
+        for (int q = 0; q < NVIEW; ++q) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][gp][q], 0, 0);
+      }
+    }
+  }
+  if constexpr (STATS != 0) {
+    // the last tile's slots, then ONE partial per block
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < 128) {
+      const int kl = t_end - 1 - t_begin;
+      const float* rp = red + (kl & 1) * 1024 + (tid >> 6) * 512 + (tid & 63);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) stat_tot += rp[sl * 64];
+      P.stats[((size_t)tr * 2 + (tid >> 6)) * P.Cout + cg * C::ROWS + (tid & 63)] = stat_tot;
     }
   }
 }
 
 int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   using C = CfgWS;
-  auto kern = P.accumulate ? conv3_ws_kernel<true> : conv3_ws_kernel<false>;
+  static const char* ws_stats_env = getenv("UNET_WS_STATS");      // tuning hook: "0" = statistics by the streaming pass
+  const bool stats_ok = !(ws_stats_env && ws_stats_env[0] == '0') && !P.accumulate && P.dst_split == P.Cout &&
+                        P.dst[0].oy == 0 && P.dst[0].ox == 0 && P.dst[0].H == P.H && P.dst[0].W == P.W;
+  const int mode = P.bn_y ? 2 : ((P.stats && stats_ok) ? 1 : 0);
+  UNET_REQUIRE(mode != 2 || stats_ok, UNET_ERR_UNSUPPORTED, "conv3_ws: fused BatchNorm backward needs one dense destination");
+  auto kern = P.accumulate ? conv3_ws_kernel<true, 0>
+                           : (mode == 2 ? conv3_ws_kernel<false, 2> : (mode == 1 ? conv3_ws_kernel<false, 1> : conv3_ws_kernel<false, 0>));
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<true, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
@@ -1664,9 +1775,9 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   const long long ranges8 = cdiv64(cdiv64(tiles, tpb), 8) * 8;      // tile ranges, padded to a multiple of 8 (XCDs)
   const long long blocks = ranges8 * nCg;
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
-  P.stats = nullptr;   // 144 weight VGPRs leave no room for per-lane running sums: BN partials by the streaming pass
-  (void)stat_parts;
-  ProfScope prof(kclass, flops, s, "conv3_ws_kernel");
+  if (mode == 0) P.stats = nullptr;               // (statistics, if wanted, by the caller's streaming pass)
+  if (stat_parts) *stat_parts = mode ? (int)ranges8 : 0;          // one ordered partial per tile range
+  ProfScope prof(kclass, flops, s, mode == 2 ? "conv3_ws_bnbwd_kernel" : "conv3_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P, tpb);
   return unet_check_launch("conv3_ws_kernel");
 }
@@ -2223,13 +2334,20 @@ inline bool dgrad_bnrelu_pdma_ok(int dtype, int n, int h, int w, int c_in_gemm, 
   return dtype == UNET_BF16 && c_in_gemm >= 128 && c_in_gemm % 64 == 0 && c_out_gemm % 64 == 0 && h % 16 == 0 &&
          w % 16 == 0 && (long long)h * w * c_out_gemm * 2 < 0x7FFFFFFFLL && (long long)h * w * c_in_gemm * 2 < 0x7FFFFFFFLL;
 }
+// 64 -> 64 (the full-resolution level): the weight-stationary streaming kernel, any frame size
+inline bool dgrad_bnrelu_ws_ok(int dtype, int n, int h, int w, int c_in_gemm, int c_out_gemm) {
+  (void)n;
+  static const char* e = getenv("UNET_WS_STATS");
+  return dtype == UNET_BF16 && c_in_gemm == 64 && c_out_gemm == 64 && (long long)h * w * 64 * 2 < 0x7FFFFFFFLL &&
+         !(e && e[0] == '0');
+}
 }  // namespace
 
 extern "C" int32_t unet_conv3x3_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_dy,
                                                        int32_t c_dx) {
   static const char* env = getenv("UNET_DGRAD_BN");       // tuning hook: "0" = never
   if (env && env[0] == '0') return 0;
-  return dgrad_bnrelu_pdma_ok(dtype, n, h, w, c_dy, c_dx) ? 1 : 0;
+  return (dgrad_bnrelu_pdma_ok(dtype, n, h, w, c_dy, c_dx) || dgrad_bnrelu_ws_ok(dtype, n, h, w, c_dy, c_dx)) ? 1 : 0;
 }
 
 extern "C" int32_t unet_conv3x3_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy, int32_t c_dy,
@@ -2259,8 +2377,11 @@ extern "C" int32_t unet_conv3x3_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h
   P.bn_scale = bn_scale; P.bn_shift = bn_shift; P.bn_mean = bn_mean;
   int parts = 0;
   hipStream_t s = (hipStream_t)stream;
-  const int32_t rc = (c_dx % 128 == 0) ? launch_pdma<128>(P, UNET_K_CONV_DGRAD, s, &parts)
-                                       : launch_pdma<64>(P, UNET_K_CONV_DGRAD, s, &parts);
+  int32_t rc;
+  if (dgrad_bnrelu_pdma_ok(dtype, n, h, w, c_dy, c_dx))
+    rc = (c_dx % 128 == 0) ? launch_pdma<128>(P, UNET_K_CONV_DGRAD, s, &parts) : launch_pdma<64>(P, UNET_K_CONV_DGRAD, s, &parts);
+  else
+    rc = launch_ws(P, UNET_K_CONV_DGRAD, s, &parts);
   *n_parts = parts;
   return rc;
 }

@@ -140,13 +140,16 @@ def validate_epoch(model, val_loader, criterion, device):
 def get_optimizer(model, optimizer_name="adam", learning_rate=1e-3, weight_decay=1e-4):
     name = optimizer_name.lower()
     params = list(model.parameters())
-    # same update rule as the reference's torch.optim.Adam(...) (src/train_utils.py:266); on the GPU the
-    # multi-tensor fused implementation (3 launches per step instead of one chain of small kernels per tensor)
-    fused = bool(params) and all(p.is_cuda for p in params)
+    # same update rule and state_dict layout as the reference's torch.optim.Adam(...) (src/train_utils.py:266); on the
+    # GPU: optim.FusedAdam = ONE libunet_hip launch over all parameter tensors per step
+    on_gpu = bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+    if name in ("adam", "adamw") and on_gpu:
+        from .optim import FusedAdam
+        return FusedAdam(params, lr=learning_rate, weight_decay=weight_decay, decoupled=(name == "adamw"))
     if name == "adam":
-        return torch.optim.Adam(params, lr=learning_rate, weight_decay=weight_decay, fused=fused)
+        return torch.optim.Adam(params, lr=learning_rate, weight_decay=weight_decay)
     if name == "adamw":
-        return torch.optim.AdamW(params, lr=learning_rate, weight_decay=weight_decay, fused=fused)
+        return torch.optim.AdamW(params, lr=learning_rate, weight_decay=weight_decay)
     if name == "sgd":
         return torch.optim.SGD(params, lr=learning_rate, momentum=0.9, weight_decay=weight_decay)
     raise ValueError(f"Unknown optimizer: {optimizer_name}")
