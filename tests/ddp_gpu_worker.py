@@ -40,8 +40,21 @@ def main():
     other = [torch.empty_like(flat) for _ in range(2)]
     dist.all_gather(other, flat)
     same = bool(torch.equal(other[0], other[1]))
+    in_place = all(p.grad.data_ptr() == net.exchange._slots[p][1].data_ptr() for p in model.parameters())
+    copies_step1 = net.exchange.copies
+    # second step on the same batch (no optimiser step in between): the buckets are rebuilt in the completion order of
+    # step 1 before this forward; same gradients must come out, again written in place
+    for p in model.parameters():
+        p.grad = None
+    recon, amap = net(image.to(dev))
+    P.CombinedLoss()(recon, amap, image.to(dev), mask.to(dev))["total_loss"].backward()
+    net.finish_gradients()
+    torch.cuda.synchronize()
+    step2_same = all(torch.equal(v.grad.cpu(), grads[k]) for k, v in model.named_parameters())
     if rank == 0:
-        torch.save({"grads": grads, "ranks_equal": same, "bucket_mb": net.exchange.bucket_sizes_mb()}, sys.argv[1])
+        torch.save({"grads": grads, "ranks_equal": same, "bucket_mb": net.exchange.bucket_sizes_mb(),
+                    "in_place": bool(in_place), "copies": int(net.exchange.copies), "copies_step1": int(copies_step1),
+                    "reordered": bool(net.exchange._reordered), "step2_same": bool(step2_same)}, sys.argv[1])
     dist.destroy_process_group()
 
 

@@ -316,6 +316,10 @@ def test_data_parallel_gradients_equal_mean_of_shard_gradients(tmp_path):
     assert worst < 1e-5, f"worst relative gradient difference {worst:.3e}"
     assert got["ranks_equal"], "the two ranks hold different reduced gradients"
     assert len(got["bucket_mb"]) >= 3
+    # the weight-gradient kernels wrote every gradient straight into its bucket slice (no per-tensor copies), and the
+    # buckets were re-laid in the completion order of step 1 without changing the result
+    assert got["in_place"] and got["copies"] == 0, got
+    assert got["reordered"] and got["step2_same"], got
 
 
 def test_gpu_preprocess_is_bit_identical_to_host_transform():

@@ -4,20 +4,28 @@ all-reduce over xGMI (``torch.distributed`` backend "nccl" IS RCCL on ROCm), ove
 The reference is single-process; this is the one parallel strategy the path needs: images are
 independent, only the gradient (43.2 M fp32 = 172.9 MB for AnomalyUNet) is exchanged, once per step.
 
-Design for xGMI (7 point-to-point links per GPU, per-link bound rings): few, LARGE buckets.  Parameters
-are bucketed in REVERSE registration order (~ the order backward produces their gradients); each bucket is
-one flat fp32 buffer.  A post-accumulate hook copies a finished gradient into its slice; when the last
-slice of a bucket lands, the all-reduce of that bucket is enqueued asynchronously (RCCL's own stream, event
-chained to the compute stream), so the big decoder/bottleneck buckets travel while the encoder backward is
-still running.  ``finish()`` waits for the outstanding collectives before the optimiser step.  BatchNorm
-statistics stay per-GPU (standard DDP semantics).
+Design for xGMI (7 point-to-point links per GPU, per-link bound rings): few, LARGE buckets, each one flat fp32
+buffer.  The weight-gradient kernels write a parameter's gradient STRAIGHT into its bucket slice (``ops.grad_out``:
+autograd adopts the slice as ``param.grad``, so there is no per-tensor copy; a gradient that arrives elsewhere -- a
+parameter that already held one -- is copied in by the post-accumulate hook).  When the last slice of a bucket has
+landed, its all-reduce is enqueued asynchronously (RCCL's own stream, chained by events to every stream that wrote a
+slice: the two decoder branches of AnomalyUNet run on two), so the big decoder/bottleneck buckets travel while the
+encoder backward is still running.  ``finish()`` waits for the outstanding collectives before the optimiser step.
+
+Bucket ORDER: the first step uses reverse registration order (~ the order backward produces gradients); the order in
+which the hooks actually fired in that step is recorded, and before the next forward the buckets are rebuilt in it -- a
+bucket then fills with gradients that complete together (registration order interleaves the two decoders, which finish
+on different streams).  BatchNorm statistics stay per-GPU (standard DDP semantics).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
+
+from . import ops
 
 
 class GradientExchange:
@@ -34,16 +42,22 @@ class GradientExchange:
         self._handles = []
         self._hooks = []
         self._events = {}
+        self._bucket_bytes = bucket_bytes
+        self._fired: List[torch.nn.Parameter] = []     # hook order of the current step
+        self._reorder = None                           # completion order to rebuild the buckets in (once)
+        self._reordered = False
+        self.copies = 0                                # gradients that had to be copied into their slice (diagnostic)
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL reduces with AVG in-kernel; gloo needs sum + scale
-        self._build(bucket_bytes)
+        self._build(bucket_bytes, list(reversed(self.params)))
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # -- layout -----------------------------------------------------------------------------
-    def _build(self, bucket_bytes: int) -> None:
-        order = list(reversed(self.params))
+    def _build(self, bucket_bytes: int, order) -> None:
+        ops.unregister_grad_slots([p.data_ptr() for p in self._slots])
+        self.buckets, self._slots, self._count = [], {}, []
         cur, cur_bytes, plan = [], 0, []
         for p in order:
             nbytes = p.numel() * 4
@@ -65,6 +79,22 @@ class GradientExchange:
             self.buckets.append(flat)
             self._count.append(len(ps))
         self._pending = list(self._count)
+        if self.world > 1:
+            ops.register_grad_slots({p.data_ptr(): (view, weakref.ref(p)) for p, (_, view) in self._slots.items()
+                                     if p.is_cuda})
+
+    def maybe_rebuild(self) -> None:
+        """Before a forward: re-bucket in the completion order recorded during the first backward (once)."""
+        order, self._reorder = self._reorder, None
+        if order is None or self._handles:
+            return
+        old = {p: view for p, (_, view) in self._slots.items()}
+        self._build(self._bucket_bytes, order)
+        for p, (_, view) in self._slots.items():          # a gradient still held keeps its values, in its new slice
+            if p.grad is not None and p.grad.data_ptr() == old[p].data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+        self._reordered = True
 
     def bucket_sizes_mb(self):
         return [round(b.numel() * 4 / 2 ** 20, 2) for b in self.buckets]
@@ -79,8 +109,13 @@ class GradientExchange:
     # -- per step ---------------------------------------------------------------------------------
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         bi, view = self._slots[p]
-        view.copy_(p.grad)
-        p.grad = view                       # the optimiser reads the reduced bucket slice
+        ops.release_grad_slot(p.data_ptr())
+        if p.grad.data_ptr() != view.data_ptr():          # not written in place (e.g. the parameter already held a gradient)
+            view.copy_(p.grad)
+            p.grad = view                   # the optimiser reads the reduced bucket slice
+            self.copies += 1
+        if not self._reordered:
+            self._fired.append(p)
         if p.is_cuda:
             # gradients of one bucket may be produced on different streams (the two decoder branches):
             # remember where each slice was written so that the collective waits for all of them
@@ -113,11 +148,24 @@ class GradientExchange:
                 self.buckets[bi].div_(self.world)
         self._handles.clear()
         self._pending = list(self._count)
+        if not self._reordered and self._reorder is None and len(self._fired) == len(self.params):
+            if [id(p) for p in self._fired] != [id(p) for ps in self._bucket_plan() for p in ps]:
+                self._reorder = list(self._fired)
+            else:
+                self._reordered = True
+        self._fired = []
+
+    def _bucket_plan(self):
+        plan = [[] for _ in self.buckets]
+        for p, (bi, _) in self._slots.items():
+            plan[bi].append(p)
+        return plan
 
     def remove(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        ops.unregister_grad_slots([p.data_ptr() for p in self._slots])
 
 
 class DataParallel(torch.nn.Module):
@@ -131,6 +179,7 @@ class DataParallel(torch.nn.Module):
         self.exchange.broadcast(list(module.parameters()) + list(module.buffers()))
 
     def forward(self, *args, **kwargs):
+        self.exchange.maybe_rebuild()
         return self.module(*args, **kwargs)
 
     def finish_gradients(self) -> None:

@@ -58,6 +58,41 @@ def _as_nhwc(t: torch.Tensor, dtype) -> torch.Tensor:
 
 _workspaces = {}
 _helpers = {}
+
+# Data parallelism (ddp.GradientExchange) registers, per parameter, the slice of its flat all-reduce bucket: the
+# weight-gradient kernels then write the gradient THERE (autograd adopts the returned tensor as ``param.grad`` when
+# the parameter has no gradient yet), so no per-tensor copy into the bucket exists.
+_grad_slots = {}           # parameter data_ptr -> (bucket view shaped like the parameter, weakref to the parameter)
+_grad_taken = set()        # slots handed out in the current backward pass (a parameter used twice gets fresh memory)
+
+
+def register_grad_slots(slots):
+    _grad_slots.update(slots)
+
+
+def unregister_grad_slots(keys):
+    for k in keys:
+        _grad_slots.pop(k, None)
+        _grad_taken.discard(k)
+
+
+def release_grad_slot(key):
+    """The gradient of this parameter has been accumulated (post-accumulate hook): its slot may be handed out again."""
+    _grad_taken.discard(key)
+
+
+def grad_out(shape, device, key):
+    """fp32 output tensor for the gradient of the parameter whose ``data_ptr()`` is ``key``: its registered bucket
+    slice when the parameter holds no gradient yet (autograd then adopts the slice as ``param.grad``), else fresh memory."""
+    slot = _grad_slots.get(key) if _grad_slots else None
+    if slot is not None:
+        view, ref = slot
+        prm = ref()
+        if prm is not None and prm.grad is None and key not in _grad_taken and tuple(view.shape) == tuple(shape) \
+                and view.device == device:
+            _grad_taken.add(key)
+            return view.detach()            # a fresh alias: autograd adopts a gradient only if nobody else holds the tensor
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
 WGRAD_SIDE_STREAM = __import__("os").environ.get("UNET_WGRAD_STREAM", "0") != "0"   # measured slower (-3 %): off
 
 
@@ -364,13 +399,13 @@ def _bn_stats_conv(lib, dt, n, h, w, src, wp, co, y, gamma, beta, running_mean, 
             "unet_bn_finalize_partials")
 
 
-def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, st, frozen=False):
+def _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, out_sink, dev, st, frozen=False, beta_key=None):
     """Gradient w.r.t. the raw conv output of a conv-BN-ReLU layer -> (dy, dgamma/dbeta [2, C]).  Premasked path: the
     consumer's data-gradient kernel already applied the ReLU mask and reduced the BatchNorm-backward sums (BnLink).
     ``frozen``: the layer normalised with its running statistics (BatchNorm2d in eval mode inside a training graph)."""
     n, co, h, w = y.shape
     pixels = n * h * w
-    dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
+    dgb = (grad_out(gamma.shape, dev, gamma.data_ptr()), grad_out(gamma.shape, dev, beta_key))
     if link is not None and link.dz_ptr and link.dz_ptr == da.data_ptr() and da.dtype == dtype and _is_nhwc(da):
         dy = da
         ws = _workspace(3 * co * 4, dev)
@@ -455,6 +490,8 @@ class ConvBnRelu(torch.autograd.Function):
                                              BN_EPS, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), st),
                     "unet_bn_eval_coeffs4")
         ctx.geom = (oy, ox, training)
+        ctx.keys = (weight.data_ptr(), beta.data_ptr(), 0 if head_w is None else head_w.data_ptr(),
+                    0 if head_b is None else head_b.data_ptr())          # gradient bucket slots (data parallelism)
         ctx.sink0 = getattr(x0, "_unet_sink", None)     # x0 is a skip with a shared gradient buffer
         ctx.out_sink = None                              # set by share_grad() when THIS output is a skip
         ctx.in_link = in_link if (in_link is not None and in_link.y is not None and x1 is None) else None
@@ -489,7 +526,6 @@ class ConvBnRelu(torch.autograd.Function):
         ctot = c0 + (0 if x1 is None else x1.shape[1])
         lib, st, dev = L.lib(), _stream(), x0.device
         pixels = n * h * w
-        dgb = torch.empty((2, co), dtype=torch.float32, device=dev)
         dhw = dhb = None
         link = ctx.out_link
         if ctx.head is not None:
@@ -498,8 +534,9 @@ class ConvBnRelu(torch.autograd.Function):
             hc = head_w.shape[0]
             dout = da.contiguous().float()
             dy = _nhwc_empty(n, co, h, w, dtype, dev)
-            dhw = torch.empty_like(head_w, dtype=torch.float32)
-            dhb = torch.empty(hc, dtype=torch.float32, device=dev)
+            dgb = (grad_out(gamma.shape, dev, gamma.data_ptr()), grad_out(gamma.shape, dev, ctx.keys[1]))
+            dhw = grad_out(head_w.shape, dev, ctx.keys[2])
+            dhb = grad_out((hc,), dev, ctx.keys[3])
             part = torch.empty((lib.unet_head_bnrelu_max_parts(), 2, co), dtype=torch.float32, device=dev)
             nparts = C.c_int32(0)
             ws = _workspace(lib.unet_head_bwd_workspace(n, h, w, co, hc), dev)
@@ -513,7 +550,7 @@ class ConvBnRelu(torch.autograd.Function):
                                               _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
         else:
             dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, ctx.out_sink, dev, st,
-                                        frozen=not training)
+                                        frozen=not training, beta_key=ctx.keys[1])
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
         dw = None
         wgrad_done = None
@@ -526,7 +563,7 @@ class ConvBnRelu(torch.autograd.Function):
                 helper.wait_stream(cur)
                 torch.cuda.set_stream(helper)
             try:
-                dw = torch.empty_like(weight, dtype=torch.float32)
+                dw = grad_out(weight.shape, dev, ctx.keys[0])
                 need = lib.unet_conv3x3_wgrad_workspace(n, h, w, ctot, co)
                 ws2 = _workspace(need, dev)
                 L.check(lib.unet_conv3x3_wgrad(dt, n, h, w, src, _ptr(dy), co, _ptr(dw), ci, _ptr(ws2), ws2.numel(),
@@ -612,6 +649,7 @@ class FirstConvBnRelu(torch.autograd.Function):
                 "unet_bn_relu_apply")
         ctx.save_for_backward(x, y, weight, gamma, coef)
         ctx.training = training
+        ctx.keys = (weight.data_ptr(), beta.data_ptr())
         ctx.out_sink = None
         ctx.out_link = None
         if out_link is not None and training:
@@ -628,10 +666,10 @@ class FirstConvBnRelu(torch.autograd.Function):
         co = weight.shape[0]
         lib, st, dev = L.lib(), _stream(), x.device
         dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, ctx.out_link, ctx.out_sink, dev, st,
-                                    frozen=not ctx.training)
+                                    frozen=not ctx.training, beta_key=ctx.keys[1])
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, dtype=torch.float32)
+            dw = grad_out(weight.shape, dev, ctx.keys[0])
             need = lib.unet_conv3x3_first_wgrad_workspace(n, h, w)
             ws2 = _workspace(need, dev)
             L.check(lib.unet_conv3x3_first_wgrad(n, h, w, _ptr(x), ci, _ptr(dy), _ptr(dw), _ptr(ws2), ws2.numel(), st),
@@ -740,6 +778,7 @@ class ConvT2x2(torch.autograd.Function):
         L.check(L.lib().unet_convt2x2_fwd(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(wp), _ptr(bias), _ptr(y), co,
                                           _stream()), "unet_convt2x2_fwd")
         ctx.save_for_backward(x, weight)
+        ctx.keys = (weight.data_ptr(), bias.data_ptr())
         return y
 
     @staticmethod
@@ -756,8 +795,8 @@ class ConvT2x2(torch.autograd.Function):
             dx = _nhwc_empty(n, ci, h, w, dtype, dev)
             L.check(lib.unet_convt2x2_dgrad(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(dx), ci, st),
                     "unet_convt2x2_dgrad")
-        dw = torch.empty_like(weight, dtype=torch.float32)
-        db = torch.empty(co, dtype=torch.float32, device=dev)
+        dw = grad_out(weight.shape, dev, ctx.keys[0])
+        db = grad_out((co,), dev, ctx.keys[1])
         ws = _workspace(lib.unet_convt2x2_wgrad_workspace(n, h, w, ci, co), dev)
         L.check(lib.unet_convt2x2_wgrad(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(dy), co, _ptr(dw), _ptr(db),
                                         _ptr(ws), ws.numel(), st), "unet_convt2x2_wgrad")
@@ -802,6 +841,7 @@ class Head(torch.autograd.Function):
                                       int(sigmoid), _ptr(out), _stream()), "unet_head_fwd")
         ctx.save_for_backward(x, weight, out)
         ctx.sigmoid = bool(sigmoid)
+        ctx.keys = (weight.data_ptr(), bias.data_ptr())
         return out
 
     @staticmethod
@@ -812,8 +852,8 @@ class Head(torch.autograd.Function):
         lib, dev = L.lib(), x.device
         dout = dout.contiguous().float()
         dx = _nhwc_empty(n, ci, h, w, x.dtype, dev)
-        dw = torch.empty_like(weight, dtype=torch.float32)
-        db = torch.empty(co, dtype=torch.float32, device=dev)
+        dw = grad_out(weight.shape, dev, ctx.keys[0])
+        db = grad_out((co,), dev, ctx.keys[1])
         ws = _workspace(lib.unet_head_bwd_workspace(n, h, w, ci, co), dev)
         L.check(lib.unet_head_bwd(_DT[x.dtype], _ptr(x), _ptr(out), _ptr(dout), n, h, w, ci, _ptr(weight), co,
                                   int(ctx.sigmoid), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
