@@ -55,6 +55,10 @@ typedef struct unet_view {
 int32_t unet_abi_version(void);
 const char* unet_last_error(void);
 
+/* The UNET_* tuning variables are read once, at the first launch that consults them; this re-reads
+ * them (same-process A/B tools such as tools/bench_layer.py --ab). */
+int32_t unet_tuning_reload(void);
+
 /* ---- per-kernel-class timing (used by bench.py for the roofline object) -------------- */
 enum unet_kclass {
   UNET_K_CONV_FWD = 0, UNET_K_CONV_DGRAD, UNET_K_CONV_WGRAD, UNET_K_CONVT_FWD, UNET_K_CONVT_DGRAD,

@@ -362,7 +362,8 @@ def test_fused_multi_tensor_adam_matches_torch(decoupled):
         assert maxabs(g, r) <= 2e-6 * max(1.0, float(r.abs().max())), (tuple(r.shape), maxabs(g, r))
     sd = got.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
-    assert maxabs(sd["state"][5]["exp_avg_sq"], ref.state_dict()["state"][5]["exp_avg_sq"]) < 1e-6
+    v_ref = ref.state_dict()["state"][5]["exp_avg_sq"]
+    assert maxabs(sd["state"][5]["exp_avg_sq"], v_ref) < 2e-6 * max(1.0, float(v_ref.abs().max()))
     # a torch optimiser takes the fused one's state and continues identically (checkpoint interchange)
     ref2_p = [p.detach().clone().cpu().requires_grad_(True) for p in got_p]
     ref2 = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref2_p, **kw)

@@ -35,6 +35,7 @@ _i, _l, _f, _p, _z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 SIGNATURES = {
     "unet_abi_version": (_i, []),
     "unet_last_error": (C.c_char_p, []),
+    "unet_tuning_reload": (_i, []),
     "unet_prof_enable": (_i, [_i]),
     "unet_prof_collect": (_i, [_p, _p, _p]),
     "unet_prof_kernel_stats": (_i, [_i, _p, _p, _p, _p]),

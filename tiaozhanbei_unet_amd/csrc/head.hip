@@ -476,11 +476,7 @@ int32_t launch_head_bwd_tile(const void* x, const float* out, const float* dout,
   constexpr int LDS = 4 * (TILE + CO * 256);
   static_assert(LDS >= 4 * (CO * 65 + 128) * 4, "reduction scratch fits the tile area");
   auto kern = head_bwd_tile_kernel<T, CO, BN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), LDS);
   hipLaunchKernelGGL(kern, dim3(nb), dim3(256), LDS, s, (const T*)x, out, dout, pixels, hw, w, sigm, (T*)dx, part,
                      bn_scale, bn_shift, bn_mean, bn_part);
   return unet_check_launch("head_bwd_tile_kernel");

@@ -832,26 +832,17 @@ int32_t launch3(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_par
   using C = Cfg3<T, BN, KG>;
   IgemmParams P = Pin;
   auto kern = conv3_kernel<T, BN, KG>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "conv3: grid of %lld blocks", blocks);
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   if constexpr (sizeof(T) == 2 && BN == 128 && KG == 4) {
     // default: the 16x16x32 MFMA variant (up to 7 % faster in interleaved A/B runs: the chip holds a
     // higher clock on that shape); UNET_CONV_VAR=0 selects the 32x32x16 kernel (tuning hook)
-    const char* var = getenv("UNET_CONV_VAR");
-    if (!(var && var[0] == '0')) {
+    if (unet_tuning().conv_var != '0') {
       using CM = Cfg3M<T, BN, KG>;
       auto km = conv3m16_kernel<T, BN, KG>;
-      static bool attr_m = false;
-      if (!attr_m) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(km), hipFuncAttributeMaxDynamicSharedMemorySize, CM::LDS);
-        attr_m = true;
-      }
+      unet_set_max_lds(reinterpret_cast<const void*>(km), CM::LDS);
       if (P.stats && stat_parts) *stat_parts = P.N * P.tilesY * P.tilesX;   // epilogue writes the BN partials
       ProfScope prof(kclass, flops, s, "conv3m16_kernel");
       hipLaunchKernelGGL(km, dim3((unsigned)blocks), dim3(256), CM::LDS, s, P);
@@ -1365,11 +1356,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   const bool bnbwd = P.bn_y != nullptr;
   auto kern = bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
                     : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel);
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[bnbwd]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done[bnbwd] = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);
   const long long stat_bytes = (long long)P.N * P.tilesY * P.tilesX * 2 * P.Cout * 4;
@@ -1747,25 +1734,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 
 int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   using C = CfgWS;
-  static const char* ws_stats_env = getenv("UNET_WS_STATS");      // tuning hook: "0" = statistics by the streaming pass
-  const bool stats_ok = !(ws_stats_env && ws_stats_env[0] == '0') && !P.accumulate && P.dst_split == P.Cout &&
+  // (UNET_WS_STATS=0: statistics by the streaming pass)
+  const bool stats_ok = unet_tuning().ws_stats != '0' && !P.accumulate && P.dst_split == P.Cout &&
                         P.dst[0].oy == 0 && P.dst[0].ox == 0 && P.dst[0].H == P.H && P.dst[0].W == P.W;
   const int mode = P.bn_y ? 2 : ((P.stats && stats_ok) ? 1 : 0);
   UNET_REQUIRE(mode != 2 || stats_ok, UNET_ERR_UNSUPPORTED, "conv3_ws: fused BatchNorm backward needs one dense destination");
   auto kern = P.accumulate ? conv3_ws_kernel<true, 0>
                            : (mode == 2 ? conv3_ws_kernel<false, 2> : (mode == 1 ? conv3_ws_kernel<false, 1> : conv3_ws_kernel<false, 0>));
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<true, 0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_ws_kernel<false, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
   P.tilesX = cdiv(P.W, C::WTW);
   P.tilesY = cdiv(P.H, C::WTH);
   const long long tiles = (long long)P.N * P.tilesY * P.tilesX;
@@ -1972,11 +1947,7 @@ template <int CIN>
 int32_t launch_convt_ws(ConvTParams P, hipStream_t s) {
   using C = CfgTW<CIN>;
   auto kern = convt_ws_kernel<CIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long total_px = (long long)P.N * P.H * P.W;
   P.tiles = (int)cdiv64(total_px, C::TP);
   const int nCg = 4 * P.Cout / 256;
@@ -2136,11 +2107,7 @@ template <int COUT>
 int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s) {
   using C = CfgTD<COUT>;
   auto kern = convt_dgrad_ws_kernel<COUT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long total_px = (long long)P.N * P.H * P.W;
   P.tiles = (int)cdiv64(total_px, C::TP);
   int tpb = (int)cdiv64(P.tiles, 256);
@@ -2159,11 +2126,7 @@ int32_t launch(const IgemmParams& Pin, int kclass, hipStream_t s) {
   IgemmParams P = Pin;
   P.stats = nullptr;
   auto kern = igemm_kernel<T, TAPS, BN, KG>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long blocks = (long long)P.N * P.tilesY * P.tilesX * P.nCo * P.nZ;
   UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), UNET_ERR_UNSUPPORTED, "igemm: grid of %lld blocks", blocks);
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * TAPS * P.gtaps * P.nZ;
@@ -2197,21 +2160,18 @@ int32_t dispatch(IgemmParams& P, int kclass, hipStream_t s, int* stat_parts = nu
   P.nCo = P.Cout / (big ? 128 : 64);
   P.tilesX = cdiv(P.W, TW);
   P.tilesY = cdiv(P.H, TH);
-  static const char* impl_env = nullptr;
-  impl_env = getenv("UNET_CONV_IMPL");          // tuning hook: "0" = generic igemm_kernel, default conv3_kernel
+  const char impl = unet_tuning().conv_impl;    // UNET_CONV_IMPL: '0' = generic igemm_kernel, '2' no weight-stationary, '3' register-staged
   const bool small = planes_fit_32bit<T>(P);
-  const bool use3 = small && !(impl_env && impl_env[0] == '0');
+  const bool use3 = small && impl != '0';
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // 64-channel inputs: weight-stationary streaming kernel (impl "2" forces it off)
-    const bool ws_ok = small && P.Ctot == 64 && P.src[1].C == 0 &&
-                       !(impl_env && (impl_env[0] == '0' || impl_env[0] == '2'));
+    const bool ws_ok = small && P.Ctot == 64 && P.src[1].C == 0 && impl != '0' && impl != '2';
     if (ws_ok) return launch_ws(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9 && sizeof(T) == 2) {
     // deep layers (>= 4 input chunks: below that the un-overlapped prologue of the one block per CU costs more
     // than it saves): both operands by LDS-DMA, 512-thread blocks (impl "3" = the register-staged kernels)
-    const bool dma_ok = small && k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 &&
-                        !(impl_env && (impl_env[0] == '0' || impl_env[0] == '3'));
+    const bool dma_ok = small && k4 && P.Ctot >= 128 && P.H % 16 == 0 && P.W % 16 == 0 && impl != '0' && impl != '3';
     if (dma_ok) return big ? launch_pdma<128>(P, kclass, s, stat_parts) : launch_pdma<64>(P, kclass, s, stat_parts);
   }
   if constexpr (TAPS == 9) {
@@ -2311,8 +2271,7 @@ extern "C" int32_t unet_conv3x3_stats(int32_t dtype, int32_t n, int32_t h, int32
   P.w = (const char*)w_packed;
   P.dst_split = c_out;
   P.imul = 1; P.gtaps = 1; P.omul = 1; P.nZ = 1;
-  const char* fs = getenv("UNET_FUSED_STATS");            // tuning hook: "0" = always the streaming pass
-  P.stats = (fs && fs[0] == '0') ? nullptr : partial;
+  P.stats = unet_tuning().fused_stats == '0' ? nullptr : partial;      // (UNET_FUSED_STATS=0: always the streaming pass)
   hipStream_t s = (hipStream_t)stream;
   int parts = 0;
   int32_t rc;
@@ -2337,16 +2296,14 @@ inline bool dgrad_bnrelu_pdma_ok(int dtype, int n, int h, int w, int c_in_gemm, 
 // 64 -> 64 (the full-resolution level): the weight-stationary streaming kernel, any frame size
 inline bool dgrad_bnrelu_ws_ok(int dtype, int n, int h, int w, int c_in_gemm, int c_out_gemm) {
   (void)n;
-  static const char* e = getenv("UNET_WS_STATS");
   return dtype == UNET_BF16 && c_in_gemm == 64 && c_out_gemm == 64 && (long long)h * w * 64 * 2 < 0x7FFFFFFFLL &&
-         !(e && e[0] == '0');
+         unet_tuning().ws_stats != '0';
 }
 }  // namespace
 
 extern "C" int32_t unet_conv3x3_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_dy,
                                                        int32_t c_dx) {
-  static const char* env = getenv("UNET_DGRAD_BN");       // tuning hook: "0" = never
-  if (env && env[0] == '0') return 0;
+  if (unet_tuning().dgrad_bn == '0') return 0;            // (UNET_DGRAD_BN=0: never)
   return (dgrad_bnrelu_pdma_ok(dtype, n, h, w, c_dy, c_dx) || dgrad_bnrelu_ws_ok(dtype, n, h, w, c_dy, c_dx)) ? 1 : 0;
 }
 
@@ -2392,10 +2349,9 @@ extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_
   UNET_REQUIRE(x && w_packed && y, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: null pointer");
   UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_fwd: bad dims");
   {
-    const char* tw = getenv("UNET_CONVT_IMPL");               // tuning hook: "0" = generic igemm path
     const long long out_bytes = (long long)n * 4 * h * w * c_out * 2;
     if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_in == 128 || c_in == 256) && out_bytes < 0x7FFFFFFFLL &&
-        !(tw && tw[0] == '0')) {
+        unet_tuning().convt_impl != '0') {                     // (UNET_CONVT_IMPL=0: generic igemm path)
       ConvTParams T{(const char*)x, (char*)y, (const char*)w_packed, bias, n, h, w, c_out, 0, 0};
       return c_in == 128 ? launch_convt_ws<128>(T, (hipStream_t)stream) : launch_convt_ws<256>(T, (hipStream_t)stream);
     }
@@ -2424,10 +2380,9 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
   UNET_REQUIRE(dy && w_packed && dx, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: null pointer");
   UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad: bad dims");
   {
-    const char* tw = getenv("UNET_CONVT_IMPL");               // tuning hook: "0" = generic igemm path
     const long long in_bytes = (long long)n * 4 * h * w * c_out * 2;
     if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_out == 64 || c_out == 128) && in_bytes < 0x7FFFFFFFLL &&
-        !(tw && tw[0] == '0')) {
+        unet_tuning().convt_impl != '0') {
       ConvTParams T{(const char*)dy, (char*)dx, (const char*)w_packed, nullptr, n, h, w, c_out, 0, 0};
       return c_out == 64 ? launch_convt_dgrad_ws<64>(T, (hipStream_t)stream)
                          : launch_convt_dgrad_ws<128>(T, (hipStream_t)stream);

@@ -1,5 +1,6 @@
 // Status reporting + per-kernel-class hipEvent timing for libunet_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -27,6 +28,45 @@ int32_t unet_check_launch(const char* what) {
 
 extern "C" int32_t unet_abi_version(void) { return UNET_ABI_VERSION; }
 extern "C" const char* unet_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------ tuning hooks, LDS opt-in
+namespace {
+UnetTuning g_tuning{};
+std::once_flag g_tuning_once;
+void read_tuning() {
+  auto first = [](const char* name) -> char { const char* v = getenv(name); return (v && v[0]) ? v[0] : (char)0; };
+  g_tuning.conv_impl = first("UNET_CONV_IMPL");
+  g_tuning.conv_var = first("UNET_CONV_VAR");
+  g_tuning.fused_stats = first("UNET_FUSED_STATS");
+  g_tuning.convt_impl = first("UNET_CONVT_IMPL");
+  g_tuning.wgrad_impl = first("UNET_WGRAD_IMPL");
+  g_tuning.ws_stats = first("UNET_WS_STATS");
+  g_tuning.dgrad_bn = first("UNET_DGRAD_BN");
+}
+std::mutex g_lds_mu;
+std::vector<std::pair<int, const void*>> g_lds_done;
+}  // namespace
+
+const UnetTuning& unet_tuning() {
+  std::call_once(g_tuning_once, read_tuning);
+  return g_tuning;
+}
+
+extern "C" int32_t unet_tuning_reload(void) {
+  (void)unet_tuning();
+  read_tuning();
+  return UNET_OK;
+}
+
+void unet_set_max_lds(const void* kernel, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> l(g_lds_mu);
+  for (auto& e : g_lds_done)
+    if (e.first == dev && e.second == kernel) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  g_lds_done.emplace_back(dev, kernel);
+}
 
 // ------------------------------------------------------------------------------ profiling
 namespace {

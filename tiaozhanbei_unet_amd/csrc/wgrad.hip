@@ -467,29 +467,19 @@ template <typename T, int TAPS>
 int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_out, int kclass, hipStream_t s) {
   using C = WCfg<T, TAPS>;
   auto kern = wgrad_kernel<T, TAPS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   P.tilesX = pl.tilesX; P.tilesY = pl.tilesY; P.nR = pl.nR; P.nC = pl.nC;
   P.split = pl.split; P.tilesPerSplit = pl.tilesPerSplit;
   const long long blocks = (long long)pl.split * pl.nR * pl.nC;
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
   {
     ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)");
-    const char* impl = getenv("UNET_WGRAD_IMPL");               // tuning hook: "0" = register-staged kernel
+    const char impl = unet_tuning().wgrad_impl;                 // UNET_WGRAD_IMPL: '0' = register-staged kernel
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-      if (!(impl && impl[0] == '0')) {
-        static bool dma_attr = false;
-        if (!dma_attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WDma::LDS);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WDma::LDS);
-          dma_attr = true;
-        }
-        if (impl && impl[0] == '2')                             // "2": every tap re-reads its X fragment
+      if (impl != '0') {
+        unet_set_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<true>), WDma::LDS);
+        unet_set_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<false>), WDma::LDS);
+        if (impl == '2')                                        // "2": every tap re-reads its X fragment
           hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
         else
           hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3((unsigned)blocks), dim3(256), WDma::LDS, s, P);
@@ -766,11 +756,7 @@ int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w
   const size_t need = (size_t)nsplit * (CIN + 1) * C::NC * sizeof(float);
   UNET_REQUIRE(workspace_bytes >= need, UNET_ERR_WORKSPACE, "unet_convt2x2_wgrad: workspace %zu < %zu", workspace_bytes, need);
   auto kern = convt_wgrad_ws_kernel<CIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
-  }
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   {
     ProfScope prof(UNET_K_CONVT_WGRAD, 2.0 * px * 4.0 * C::COUT * CIN, s, "convt_wgrad_ws_kernel (+ reduce)");
     hipLaunchKernelGGL(kern, dim3(nsplit, yb), dim3(256), C::LDS, s, P);
@@ -783,10 +769,9 @@ int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w
 }
 
 inline bool convt_wgrad_ws_ok(int dtype, int n, int h, int w, int c_in, int c_out) {
-  const char* e = getenv("UNET_CONVT_IMPL");                // tuning hook: "0" = generic kernels
   const long long xb = (long long)n * h * w * c_in * 2;
   return dtype == UNET_BF16 && (c_in == 128 || c_in == 256) && c_out * 2 == c_in && w % 32 == 0 &&
-         2 * xb < 0x7FFFFFFFLL && !(e && e[0] == '0');
+         2 * xb < 0x7FFFFFFFLL && unet_tuning().convt_impl != '0';      // (UNET_CONVT_IMPL=0: generic kernels)
 }
 inline size_t convt_wgrad_ws_bytes(int n, int h, int w, int c_in) {
   const long long tiles = (long long)n * h * w / 32;

@@ -97,6 +97,7 @@ def main():
         for v in variants:
             if v is not None:
                 os.environ[a.abvar] = v
+                lib.unet_tuning_reload()
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -111,6 +112,7 @@ def main():
         outs = {}
         for v in variants:
             os.environ[a.abvar] = v
+            lib.unet_tuning_reload()
             tgt = {"fwd": y, "dgrad": dx, "wgrad": dw}[a.op]
             tgt.zero_()
             run()
