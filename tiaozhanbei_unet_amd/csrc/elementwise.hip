@@ -239,6 +239,141 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------- BatchNorm-apply + ReLU + max pool 2x2, fused
+// Encoder levels (src/model.py:18-19 followed by the next level's nn.MaxPool2d(2), :32): ONE pass reads the raw conv
+// output y, writes the activation a (the skip tensor) and its 2x2 max (the next level's input) -- the pool's own read
+// of a is gone.  A thread owns one window x 16 bytes of channels; (256 * PIECE) % C == 0, so its channel group -- and its
+// coefficients, in registers -- never change along the grid-stride loop.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ a,
+                                                               T* __restrict__ pooled, int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  const int OH = H / 2, OW = W / 2, G = C / PIECE;
+  const int WH = (H + 1) / 2, WW = (W + 1) / 2;   // windows incl. the ragged edge (its pixels get a, no pooled value)
+  const long long total = (long long)N * WH * WW * G;
+  const int g = threadIdx.x % G;
+  float sc[PIECE], sh[PIECE];
+#pragma unroll
+  for (int j = 0; j < PIECE; ++j) { sc[j] = scale[g * PIECE + j]; sh[j] = shift[g * PIECE + j]; }
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long t = i / G;
+    const int ox = (int)(t % WW);  t /= WW;
+    const int oy = (int)(t % WH);
+    const long long n = t / WH;
+    const long long base = ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    const bool ex = 2 * ox + 1 < W, ey = 2 * oy + 1 < H;
+    float v[4][PIECE];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
+      const long long o = base + ((long long)(k >> 1) * W + (k & 1)) * C;
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) v[k][j] = 0.f;
+      if (ok) {
+        Vec<T>::load(y + o, v[k]);
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) v[k][j] = ET<T>::to_f(ET<T>::from_f(fmaxf(fmaf(v[k][j], sc[j], sh[j]), 0.f)));
+        Vec<T>::store(a + o, v[k]);
+      }
+    }
+    if (oy < OH && ox < OW) {
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) v[0][j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+      Vec<T>::store(pooled + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), v[0]);
+    }
+  }
+}
+
+// Backward of the same pair for a skip tensor whose OTHER consumers have already added their gradients into da_old
+// (ops.GradSink; may be NULL): da = da_old + route(dpooled) (first maximum wins ties, as torch), then the ReLU mask of
+// this layer and the two BatchNorm-backward sums, in one pass: dz = da * [z > 0] (rounded to T exactly like the
+// unfused kernels round da), part[block][2][C] = (sum dz, sum dz * (y - mean)) -> unet_bn_bwd_premasked.  The window's
+// activations are recomputed from y (rounded like the stored ones), so a itself is not read.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dpooled,
+                                                               const T* da_old, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, T* dz,
+                                                               float* __restrict__ part, int N, int H, int W, int C) {
+  constexpr int PIECE = ET<T>::PIECE;
+  __shared__ float red[2][256][PIECE + 1];
+  const int OH = H / 2, OW = W / 2, G = C / PIECE;
+  const int WH = (H + 1) / 2, WW = (W + 1) / 2;
+  const long long total = (long long)N * WH * WW * G;
+  const int g = threadIdx.x % G;
+  float sc[PIECE], sh[PIECE], mu[PIECE], s0[PIECE], s1[PIECE];
+#pragma unroll
+  for (int j = 0; j < PIECE; ++j) {
+    sc[j] = scale[g * PIECE + j]; sh[j] = shift[g * PIECE + j]; mu[j] = mean[g * PIECE + j];
+    s0[j] = 0.f; s1[j] = 0.f;
+  }
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long t = i / G;
+    const int ox = (int)(t % WW);  t /= WW;
+    const int oy = (int)(t % WH);
+    const long long n = t / WH;
+    const long long base = ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    const bool ex = 2 * ox + 1 < W, ey = 2 * oy + 1 < H, full = oy < OH && ox < OW;
+    float yv[4][PIECE], av[4][PIECE], gr[PIECE];
+    bool on[4][PIECE];
+#pragma unroll
+    for (int j = 0; j < PIECE; ++j) gr[j] = 0.f;
+    if (full) Vec<T>::load(dpooled + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), gr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) { yv[k][j] = 0.f; av[k][j] = -1.f; on[k][j] = false; }
+      if (ok) {
+        Vec<T>::load(y + base + ((long long)(k >> 1) * W + (k & 1)) * C, yv[k]);
+#pragma unroll
+        for (int j = 0; j < PIECE; ++j) {
+          const float z = fmaf(yv[k][j], sc[j], sh[j]);
+          on[k][j] = z > 0.f;
+          av[k][j] = ET<T>::to_f(ET<T>::from_f(fmaxf(z, 0.f)));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
+      if (!ok) continue;
+      const long long o = base + ((long long)(k >> 1) * W + (k & 1)) * C;
+      float d[PIECE];
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
+      if (da_old) Vec<T>::load(da_old + o, d);
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        if (full) {
+          const float m = fmaxf(fmaxf(av[0][j], av[1][j]), fmaxf(av[2][j], av[3][j]));
+          bool first = av[k][j] == m;                  // the FIRST maximum in row-major window order takes the gradient
+#pragma unroll
+          for (int q = 0; q < 4; ++q) first = first && !(q < k && av[q][j] == m);
+          if (first) d[j] += gr[j];
+        }
+        const float da = ET<T>::to_f(ET<T>::from_f(d[j]));                 // da as the unfused kernels store it
+        const float v = ET<T>::to_f(ET<T>::from_f(on[k][j] ? da : 0.f));   // dz as stored
+        d[j] = v;
+        s0[j] += v;
+        s1[j] = fmaf(v, yv[k][j] - mu[j], s1[j]);
+      }
+      Vec<T>::store(dz + o, d);
+    }
+  }
+  // block partial: the 256 / G threads of a channel group, in thread order
+#pragma unroll
+  for (int j = 0; j < PIECE; ++j) { red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int q = c / C, ch = c - q * C, gg = ch / PIECE, j = ch - gg * PIECE;
+    float tsum = 0.f;
+    for (int k = gg; k < 256; k += G) tsum += red[q][k][j];
+    part[((size_t)blockIdx.x * 2 + q) * C + ch] = tsum;
+  }
+}
+
 // ------------------------------------------------------------------------------- bilinear x2 (align_corners)
 __device__ inline void bil_axis(int o, int n_in, int n_out, int& i0, int& i1, float& f) {
   const float src = (n_out > 1) ? o * ((float)(n_in - 1) / (float)(n_out - 1)) : 0.f;
@@ -323,8 +458,8 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
 
 // ------------------------------------------------------------------------------- Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n4, float lr, float b1, float b2, float eps,
-                            float wd, float gscale, float bc1, float bc2_sqrt) {
+                            float* __restrict__ v, long long n4, float lr, float b1, float b2, float omb1,
+                            float omb2, float eps, float wd, float gscale, float bc1, float bc2_sqrt) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
@@ -332,8 +467,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gr = fmaf(wd, pp[j], gg[j] * gscale);
-      mm[j] = b1 * mm[j] + (1.f - b1) * gr;
-      vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+      mm[j] = b1 * mm[j] + omb1 * gr;
+      vv[j] = b2 * vv[j] + omb2 * gr * gr;
       const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
       pp[j] -= (lr / bc1) * (mm[j] / denom);
     }
@@ -449,6 +584,53 @@ extern "C" int32_t unet_maxpool2_bwd(int32_t dtype, const void* x, const void* d
   UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_maxpool2_bwd: dims");
   EW_DISPATCH("maxpool2_bwd_kernel", maxpool2_bwd_kernel, (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * c,
               (const T*)x, (const T*)dy, (T*)dx, n, h, w, c, accumulate);
+}
+
+
+extern "C" int32_t unet_bn_relu_pool_supported(int32_t dtype, int32_t c) {
+  const int piece = dtype == UNET_BF16 ? 8 : 4;
+  return (c > 0 && c % piece == 0 && 256 % (c / piece) == 0) ? 1 : 0;
+}
+
+extern "C" int32_t unet_bn_relu_pool_fwd(int32_t dtype, const void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                                         const float* scale, const float* shift, void* a, void* pooled, void* stream) {
+  UNET_REQUIRE(y && scale && shift && a && pooled, UNET_ERR_BAD_ARG, "unet_bn_relu_pool_fwd: null pointer");
+  UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && unet_bn_relu_pool_supported(dtype, c), UNET_ERR_UNSUPPORTED,
+               "unet_bn_relu_pool_fwd: c=%d h=%d w=%d", c, h, w);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_BN, 0.0, s, "bn_relu_pool_fwd_kernel");
+  const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                       (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
+  else
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale, shift,
+                       (float*)a, (float*)pooled, n, h, w, c);
+  return unet_check_launch("bn_relu_pool_fwd_kernel");
+}
+
+namespace { constexpr int POOL_BWD_MAX_BLOCKS = 256 * 8; }     // = the partial-sum capacity callers allocate
+extern "C" size_t unet_bn_relu_pool_max_parts(void) { return POOL_BWD_MAX_BLOCKS; }
+
+extern "C" int32_t unet_bn_relu_pool_bwd(int32_t dtype, const void* y, const void* dpooled, const void* da_old, int32_t n,
+                                         int32_t h, int32_t w, int32_t c, const float* scale, const float* shift,
+                                         const float* mean, void* dz, float* partial, int32_t* n_parts, void* stream) {
+  UNET_REQUIRE(y && dpooled && scale && shift && mean && dz && partial && n_parts, UNET_ERR_BAD_ARG,
+               "unet_bn_relu_pool_bwd: null pointer");
+  UNET_REQUIRE(n > 0 && h >= 2 && w >= 2 && unet_bn_relu_pool_supported(dtype, c), UNET_ERR_UNSUPPORTED,
+               "unet_bn_relu_pool_bwd: c=%d h=%d w=%d", c, h, w);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(UNET_K_POOL, 0.0, s, "bn_relu_pool_bwd_kernel");
+  const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
+  const int blocks = (int)std::min<long long>(cdiv64(total, 256), POOL_BWD_MAX_BLOCKS);   // one partial per block
+  if (dtype == UNET_BF16)
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)dpooled,
+                       (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
+  else
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)y, (const float*)dpooled,
+                       (const float*)da_old, scale, shift, mean, (float*)dz, partial, n, h, w, c);
+  *n_parts = blocks;
+  return unet_check_launch("bn_relu_pool_bwd_kernel");
 }
 
 extern "C" int32_t unet_upsample_bilinear2x_fwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w,
@@ -568,19 +750,19 @@ extern "C" int32_t unet_anomaly_score(const float* recon, const float* image, in
 // updates up to ADAM_CHUNK elements of its tensor (vector path on the 16-byte-aligned body, scalar tail).
 namespace {
 constexpr int ADAM_CHUNK = 4096;
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float b1, float b2, float eps,
-                                         float wd, float gscale, float bc2_sqrt, int decoupled) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_bc1, float b1, float b2, float omb1,
+                                         float omb2, float eps, float wd, float gscale, float bc2_sqrt, int decoupled) {
   float gr = g * gscale;
   if (!decoupled) gr = fmaf(wd, p, gr);               // Adam: the L2 term joins the gradient (torch.optim.Adam)
-  m = b1 * m + (1.f - b1) * gr;
-  v = b2 * v + (1.f - b2) * gr * gr;
+  m = b1 * m + omb1 * gr;
+  v = b2 * v + omb2 * gr * gr;
   const float denom = sqrtf(v) / bc2_sqrt + eps;
   p -= lr_bc1 * (m / denom);
 }
 __global__ __launch_bounds__(256) void adam_multi_kernel(const unet_adam_desc* __restrict__ descs,
                                                          const unet_adam_chunk* __restrict__ chunks, float lr, float b1,
-                                                         float b2, float eps, float wd, float gscale, float bc1,
-                                                         float bc2_sqrt, int decoupled) {
+                                                         float b2, float omb1, float omb2, float eps, float wd,
+                                                         float gscale, float bc1, float bc2_sqrt, int decoupled) {
   const unet_adam_chunk ck = chunks[blockIdx.x];
   const unet_adam_desc d = descs[ck.tensor];
   const long long begin = ck.first, end = begin + ADAM_CHUNK < d.n ? begin + ADAM_CHUNK : d.n;
@@ -593,7 +775,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unet_adam_desc* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float pj = pp[j] * decay, mj = mm[j], vj = vv[j];
-      adam_one(pj, gg[j], mj, vj, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt, decoupled);
+      adam_one(pj, gg[j], mj, vj, lr_bc1, b1, b2, omb1, omb2, eps, wd, gscale, bc2_sqrt, decoupled);
       pp[j] = pj; mm[j] = mj; vv[j] = vj;
     }
     *reinterpret_cast<f32x4*>(d.p + i) = pp;
@@ -602,7 +784,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unet_adam_desc* _
   }
   for (long long i = vend + threadIdx.x; i < end; i += 256) {
     float pp = d.p[i] * decay, mm = d.m[i], vv = d.v[i];
-    adam_one(pp, d.g[i], mm, vv, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt, decoupled);
+    adam_one(pp, d.g[i], mm, vv, lr_bc1, b1, b2, omb1, omb2, eps, wd, gscale, bc2_sqrt, decoupled);
     d.p[i] = pp; d.m[i] = mm; d.v[i] = vv;
   }
 }
@@ -611,30 +793,30 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unet_adam_desc* _
 extern "C" int32_t unet_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
 extern "C" int32_t unet_adam_multi(const unet_adam_desc* descs, const unet_adam_chunk* chunks, int32_t n_chunks, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step,
+                                   double beta1, double beta2, float eps, float weight_decay, float grad_scale, int32_t step,
                                    int32_t decoupled, void* stream) {
   UNET_REQUIRE(descs && chunks && n_chunks > 0 && step >= 1, UNET_ERR_BAD_ARG, "unet_adam_multi: bad argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_OTHER, 0.0, s, "adam_multi_kernel");
-  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, descs, chunks, lr, beta1, beta2, eps,
-                     weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2), decoupled);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, descs, chunks, lr, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2), decoupled);
   return unet_check_launch("adam_multi_kernel");
 }
 
 extern "C" int32_t unet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float lr, double beta1, double beta2, float eps, float weight_decay,
                                   float grad_scale, int32_t step, void* stream) {
   UNET_REQUIRE(param && grad && exp_avg && exp_avg_sq, UNET_ERR_BAD_ARG, "unet_adam_step: null pointer");
   UNET_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, UNET_ERR_BAD_ARG, "unet_adam_step: n=%lld (must be a multiple of 4), step=%d",
                (long long)n, step);
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_OTHER, 0.0, s);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
-                     (long long)(n / 4), lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1,
+                     (long long)(n / 4), lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, grad_scale, (float)bc1,
                      (float)sqrt(bc2));
   return unet_check_launch("adam_kernel");
 }

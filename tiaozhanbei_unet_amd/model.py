@@ -53,7 +53,7 @@ class _HipBlock(nn.Module):
 
 
 def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, first: bool = False, in_link=None, out_link=None,
-                  head=None):
+                  head=None, pool=False):
     """One conv3x3 -> BatchNorm2d -> ReLU third of DoubleConv.  Batch vs running statistics follow ``bn.training``
     (the holder module itself, so a frozen ``bn.eval()`` inside a training model is honoured like in the reference's
     nn.Sequential); ``bn.momentum is None`` is torch's cumulative moving average (factor 1 / num_batches_tracked).
@@ -75,7 +75,7 @@ def _conv_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, x_up, first: bool = Fa
         fold = (not track) and not torch.is_grad_enabled()
         hw, hb, hs = (head[0].conv.weight, head[0].conv.bias, head[1]) if head is not None else (None, None, False)
         out = ops.ConvBnRelu.apply(x, x_up, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   track, momentum, fold, in_link, out_link, hw, hb, hs)
+                                   track, momentum, fold, in_link, out_link, hw, hb, hs, pool)
     if training and bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -124,11 +124,13 @@ class DoubleConv(_HipBlock):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x, x_up=None, head=None):
+    def forward(self, x, x_up=None, head=None, pool=False):
         """``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
         tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly.
         ``head`` (internal, optional): (OutConv, sigmoid) applied to the result -- in training mode the 1x1 head
-        is fused with the last BatchNorm + ReLU (the activation is never written)."""
+        is fused with the last BatchNorm + ReLU (the activation is never written).
+        ``pool`` (internal, optional): also return ``max_pool2d(result, 2)`` -- in training mode the pool is fused with
+        the last BatchNorm + ReLU (forward) and with its backward (see ops.ConvBnRelu)."""
         seq = self.double_conv
         # the intermediate activation has exactly one consumer (the second convolution): its ReLU mask and
         # BatchNorm-backward sums are produced by that convolution's data-gradient kernel (ops.BnLink)
@@ -141,9 +143,13 @@ class DoubleConv(_HipBlock):
             if x_up is not None:
                 x_up = ops.to_operator_layout(x_up, self.compute_dtype)
             a = _conv_bn_relu(seq[0], seq[1], x, x_up, out_link=link)
-        out = _conv_bn_relu(seq[3], seq[4], a, None, in_link=link, head=head if fuse_head else None)
+        fuse_pool = pool and ops.FUSE_BN_POOL and seq[4].training and a.shape[2] >= 2 and a.shape[3] >= 2 and \
+            bool(ops.L.lib().unet_bn_relu_pool_supported(ops._DT[a.dtype], seq[3].out_channels))
+        out = _conv_bn_relu(seq[3], seq[4], a, None, in_link=link, head=head if fuse_head else None, pool=fuse_pool)
         if head is not None and not fuse_head:
             out = head[0](out, sigmoid=head[1])
+        if pool and not fuse_pool:
+            return out, None
         return out
 
 
@@ -155,9 +161,13 @@ class Down(_HipBlock):
         self.precision = precision
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels, precision=precision))
 
-    def forward(self, x):
-        x = ops.to_operator_layout(x, self.compute_dtype)
-        return self.maxpool_conv[1](ops.MaxPool2.apply(x))
+    def forward(self, x, pooled=None, pool=False):
+        """``pooled`` (internal, optional): ``max_pool2d(x, 2)`` already computed by the producer of ``x`` (fused with its
+        BatchNorm + ReLU); ``pool``: see DoubleConv.forward."""
+        if pooled is None:
+            x = ops.to_operator_layout(x, self.compute_dtype)
+            pooled = ops.MaxPool2.apply(x)
+        return self.maxpool_conv[1](pooled, pool=pool)
 
 
 class Up(_HipBlock):
@@ -234,12 +244,17 @@ def _side_stream(device):
 
 
 def _encoder(m, x):
-    # x1..x4 feed the next level AND the decoder(s): their gradients meet in one buffer (ops.GradSink)
-    x1 = ops.share_grad(m.inc(x))
-    x2 = ops.share_grad(m.down1(x1))
-    x3 = ops.share_grad(m.down2(x2))
-    x4 = ops.share_grad(m.down3(x3))
-    x5 = m.down4(x4)
+    # x1..x4 feed the next level AND the decoder(s): their gradients meet in one buffer (ops.GradSink); each level
+    # also hands its max-pooled activation to the next one (fused with its last BatchNorm + ReLU when training)
+    x1, p1 = m.inc(x, pool=True)
+    x1 = ops.share_grad(x1)
+    x2, p2 = m.down1(x1, pooled=p1, pool=True)
+    x2 = ops.share_grad(x2)
+    x3, p3 = m.down2(x2, pooled=p2, pool=True)
+    x3 = ops.share_grad(x3)
+    x4, p4 = m.down3(x3, pooled=p3, pool=True)
+    x4 = ops.share_grad(x4)
+    x5 = m.down4(x4, pooled=p4)
     return x1, x2, x3, x4, x5
 
 

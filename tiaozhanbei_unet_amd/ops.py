@@ -366,6 +366,7 @@ def _folded_pack(weight, gamma, beta, running_mean, running_var, co, ctot, dtype
 # ----------------------------------------------------------------------------- conv3x3 + BN + ReLU
 FUSE_BN_BWD = __import__("os").environ.get("UNET_FUSE_BN_BWD", "1") != "0"      # tuning hook (A/B runs)
 FUSE_BN_HEAD = __import__("os").environ.get("UNET_FUSE_BN_HEAD", "1") != "0"
+FUSE_BN_POOL = __import__("os").environ.get("UNET_FUSE_BN_POOL", "1") != "0"
 
 
 class BnLink:
@@ -441,11 +442,15 @@ class ConvBnRelu(torch.autograd.Function):
         reads the RAW conv output and applies BatchNorm + ReLU on load, its backward writes the ReLU-masked gradient
         and the BatchNorm-backward sums -- no activation tensor, no BN-apply pass, no (y, da) reduction pass.
         The function then returns the head's NCHW fp32 output.
-      * ``out_link`` / ``in_link`` (BnLink): see BnLink."""
+      * ``out_link`` / ``in_link`` (BnLink): see BnLink.
+      * ``pool``: the layer closes an encoder level (src/model.py:18-19, next level's MaxPool2d :32): BatchNorm-apply +
+        ReLU + 2x2 max pool in one pass; returns (a, maxpool2(a)).  The backward routes the pooled gradient, adds it to
+        what the decoders left in the skip's gradient buffer, masks and reduces in one pass (no separate pool backward,
+        no (y, da) reduction pass)."""
 
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, training, momentum, fold=False,
-                in_link=None, out_link=None, head_w=None, head_b=None, head_sigmoid=False):
+                in_link=None, out_link=None, head_w=None, head_b=None, head_sigmoid=False, pool=False):
         _require_cuda(x0, weight)
         dtype = x0.dtype
         dt = _DT[dtype]
@@ -461,8 +466,8 @@ class ConvBnRelu(torch.autograd.Function):
         ctot = c0 + c1
         if not (ci <= ctot < ci + 64):
             raise ValueError(f"conv weight expects {ci} input channels, activations carry {ctot}")
-        if head_w is not None and not training:
-            raise RuntimeError("ConvBnRelu: the fused head is a training-path fusion")
+        if (head_w is not None or pool) and not training:
+            raise RuntimeError("ConvBnRelu: the fused head / pool are training-path fusions")
         lib, st, dev = L.lib(), _stream(), x0.device
         y = _nhwc_empty(n, co, h, w, dtype, dev)
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
@@ -497,6 +502,16 @@ class ConvBnRelu(torch.autograd.Function):
         ctx.in_link = in_link if (in_link is not None and in_link.y is not None and x1 is None) else None
         ctx.out_link = None
         ctx.head = None
+        ctx.pool = False
+        if pool:
+            a = _nhwc_empty(n, co, h, w, dtype, dev)
+            pooled = _nhwc_empty(n, co, h // 2, w // 2, dtype, dev)
+            L.check(lib.unet_bn_relu_pool_fwd(dt, _ptr(y), n, h, w, co, _ptr(coef[2]), _ptr(coef[3]), _ptr(a),
+                                              _ptr(pooled), st), "unet_bn_relu_pool_fwd")
+            ctx.save_for_backward(x0, x1, y, weight, gamma, coef)
+            ctx.pool = True
+            ctx.set_materialize_grads(False)
+            return a, pooled
         if head_w is not None:
             hc = head_w.shape[0]
             out = torch.empty((n, hc, h, w), dtype=torch.float32, device=dev)
@@ -515,7 +530,7 @@ class ConvBnRelu(torch.autograd.Function):
         return a
 
     @staticmethod
-    def backward(ctx, da):
+    def backward(ctx, da, dpooled=None):
         saved = ctx.saved_tensors
         x0, x1, y, weight, gamma, coef = saved[:6]
         oy, ox, training = ctx.geom
@@ -548,7 +563,27 @@ class ConvBnRelu(torch.autograd.Function):
             L.check(lib.unet_bn_bwd_premasked(dt, _ptr(dy), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]),
                                               _ptr(coef[1]), _ptr(part), nparts.value, _ptr(dgb[0]), _ptr(dgb[1]),
                                               _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
+        elif ctx.pool and dpooled is not None:
+            # pooled gradient routed + added to the skip's gradient buffer + ReLU mask + BatchNorm-backward sums: one pass
+            if da is not None:
+                if ctx.out_sink is not None:
+                    ctx.out_sink.collect(da, dev)
+                da = _as_nhwc(da, dtype)
+            dpooled = _as_nhwc(dpooled, dtype)
+            dy = da if da is not None else _nhwc_empty(n, co, h, w, dtype, dev)      # in place over the skip's buffer
+            part = torch.empty((lib.unet_bn_relu_pool_max_parts(), 2, co), dtype=torch.float32, device=dev)
+            nparts = C.c_int32(0)
+            L.check(lib.unet_bn_relu_pool_bwd(dt, _ptr(y), _ptr(dpooled), _ptr(da), n, h, w, co, _ptr(coef[2]),
+                                              _ptr(coef[3]), _ptr(coef[0]), _ptr(dy), _ptr(part), C.byref(nparts), st),
+                    "unet_bn_relu_pool_bwd")
+            dgb = (grad_out(gamma.shape, dev, gamma.data_ptr()), grad_out(gamma.shape, dev, ctx.keys[1]))
+            ws = _workspace(3 * co * 4, dev)
+            L.check(lib.unet_bn_bwd_premasked(dt, _ptr(dy), _ptr(y), pixels, co, _ptr(gamma), _ptr(coef[0]),
+                                              _ptr(coef[1]), _ptr(part), nparts.value, _ptr(dgb[0]), _ptr(dgb[1]),
+                                              _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
         else:
+            if da is None:                       # (a pooled pair whose skip half nobody used, and no pooled gradient)
+                da = torch.zeros_like(y)
             dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, link, ctx.out_sink, dev, st,
                                         frozen=not training, beta_key=ctx.keys[1])
         src = _views([(x0, 0, 0), None if x1 is None else (x1, oy, ox)])
@@ -608,7 +643,7 @@ class ConvBnRelu(torch.autograd.Function):
                         dx0 = None              # already inside the buffer the first consumer returned
         if wgrad_done is not None:
             torch.cuda.current_stream(dev).wait_event(wgrad_done)
-        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, dhw, dhb, None
+        return dx0, dx1, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, dhw, dhb, None, None
 
 
 class FirstConvBnRelu(torch.autograd.Function):
