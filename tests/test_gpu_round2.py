@@ -367,7 +367,7 @@ def test_fused_multi_tensor_adam_matches_torch(decoupled):
     # a torch optimiser takes the fused one's state and continues identically (checkpoint interchange)
     ref2_p = [p.detach().clone().cpu().requires_grad_(True) for p in got_p]
     ref2 = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref2_p, **kw)
-    ref2.load_state_dict({"state": {k: {n: (t.cpu() if torch.is_tensor(t) else t) for n, t in v.items()}
+    ref2.load_state_dict({"state": {k: {n: (t.detach().clone().cpu() if torch.is_tensor(t) else t) for n, t in v.items()}
                                     for k, v in sd["state"].items()},
                           "param_groups": [{k: v for k, v in ref2.state_dict()["param_groups"][0].items()}]})
     got.grad_scale = 1.0

@@ -901,7 +901,15 @@ struct CfgP {
   static constexpr int NST = CT / 2 * 4;                             // 16-byte output stores per lane per work item
 };
 
-template <int BN, bool BNBWD = false>
+// PP ("ping-pong"): the two waves of a SIMD (w, w + 4) run HALF A STEP apart.  Waves 0-3 own the tile's first BN/2
+// output channels, waves 4-7 the second; a step is [LOAD: 16 fragment reads of the tap, this wave's LDS-DMA issues, the
+// counted vmcnt, lgkmcnt(0)] s_barrier [COMPUTE: the tap's 32 MFMAs straight from registers] s_barrier, and waves 4-7
+// start one barrier late -- while one wave of a SIMD feeds the matrix pipe its partner reads LDS and issues DMAs,
+// instead of all eight bursting their DMAs and fragment reads together behind one barrier per tap (stamps: 35-45 % of a
+// lock-step tap went to the DMA issue burst, profiles/r02_pdma_stamps.txt).  LDS hazards at distance one barrier: a
+// slab / patch buffer is re-filled by DMAs issued in the slot after its last reads, which are retired (lgkmcnt(0))
+// BEFORE the barrier that ends their LOAD.
+template <int BN, bool BNBWD = false, bool PP = false>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   using C = CfgP<BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -909,7 +917,8 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave & 1, wpx = wave >> 1;
+  const int grp = wave >> 2;                     // PP: 0 = the leading half, 1 = one barrier behind
+  const int wco = PP ? grp : (wave & 1), wpx = PP ? (wave & 3) : (wave >> 1);
   const int l15 = lane & 15, kb = lane >> 4;
 
   const int G = gridDim.x;                       // launch_pdma makes it a multiple of 8
@@ -1059,16 +1068,45 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
   };
 
+  // PP: the same tap as two halves -- every fragment of the tap into registers, then nothing but MFMAs
+  bf16x8 fa[2][C::CT], fb[2][4];
+  auto load_frags = [&](int pbuf, int toff, int slot) {
+    const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
+    const char* pb = smem + pbuf + toff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) fb[ks][pt] = *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64);
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct) fa[ks][ct] = *reinterpret_cast<const bf16x8*>(pa + aoff[ct][ks]);
+    }
+  };
+  auto mma_frags = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][ct], fb[ks][pt], acc[ct][pt], 0, 0, 0);
+  };
+
   // prologue: patch of chunk 0 and the first two weight slabs of the first work item
   setup_dma(logical);
 #pragma unroll
   for (int j = 0; j < C::NDA; ++j) dma_patch(0, j, 0, true);
   dma_w(d_wbase, 0, 0, 0, true);
   dma_w(d_wbase, 0, 1, 1, true);
+  if constexpr (PP) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");      // patch 0 + W(0) landed; W(1) in flight
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();                              // the stagger: waves 4-7 one barrier behind
+  }
 
 #ifdef PDMA_STAMPS
   // diagnostic build: per-wave cycle sums of (vmcnt wait, barrier, DMA issue, fragment reads + MFMAs) over all taps
-  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0, st_taps = 0, st_epi = 0;
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0, st_taps = 0, st_epi = 0, st_b2 = 0, st_rd = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
   bool after_epilogue = false;
@@ -1095,6 +1133,63 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         if (has_next) setup_dma(wk + G);
       }
       const int pbuf = pbuf_i * C::A_BYTES;
+      if constexpr (PP) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          // ---- LOAD
+#ifdef PDMA_STAMPS
+          const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+          if (st_prev) st_b2 += st_a - st_prev;
+#endif
+          load_frags(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef PDMA_STAMPS
+          st_rd += __builtin_amdgcn_s_memtime() - st_a;
+#endif
+          if (tap < C::NDA) dma_patch(last ? 0 : c + 1, tap, pbuf_i ^ 1, last ? d_live : true);
+          if (tap + 2 < 9) dma_w(c_wbase, c, tap + 2, (tap + 2) % 3, true);
+          else if (!last) dma_w(c_wbase, c + 1, tap + 2 - 9, (tap + 2) % 3, true);
+          else dma_w(d_wbase, 0, tap + 2 - 9, (tap + 2) % 3, d_live);
+          // everything older than THIS phase's DMAs has landed: the next step's weight slab (issued one step ago) and,
+          // by then, every patch piece of the next chunk [the previous work item's output stores sit in between]
+#ifdef PDMA_STAMPS
+          const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+          st_sum[0] += st_b - st_a;
+#endif
+          if (tap == 0 && c == 0 && after_epilogue) {                  // (tap 0 always carries a patch piece)
+            if (P.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + C::NDW + C::NST + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + C::NDW + C::NST) : "memory");
+          } else if (tap < C::NDA) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + C::NDW) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PDMA_STAMPS
+          const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+          st_sum[1] += st_c - st_b;
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef PDMA_STAMPS
+          const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+          st_sum[2] += st_d - st_c;
+#endif
+          // ---- COMPUTE
+          __builtin_amdgcn_s_setprio(1);
+          mma_frags();
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef PDMA_STAMPS
+          st_prev = __builtin_amdgcn_s_memtime();
+          st_sum[3] += st_prev - st_d;
+          st_taps += 1;
+#endif
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #ifdef PDMA_STAMPS
@@ -1131,11 +1226,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #endif
         compute(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
       }
+      }
       pbuf_i ^= 1;
     }
 
 #ifdef PDMA_STAMPS
-    { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_sum[3] += t - st_prev; st_prev = 0; st_epi -= t; }
+    { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (!PP) st_sum[3] += t - st_prev; st_prev = 0; st_epi -= t; }
 #endif
     // ---- epilogue: D of 16x16x32: col = lane&15 (pixel), rows (lane>>4)*4 + reg (4 consecutive channels).
     // Buffer stores (out-of-range offset = dropped) so every lane issues exactly NST of them.
@@ -1308,8 +1404,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       const int part = P.zdiv ? logical : (n * P.tilesY + tyi) * P.tilesX + txi;
       float tsum = 0.f;
       unsigned so = OOB;
-      if (tid < 2 * BN) {
-        const int q = tid / BN, cl = tid - q * BN;
+      // PP: the barrier above is this half's own exchange (the other half is a barrier apart); a half owns BN/2
+      // channels outright, so its BN threads (statistic, channel) total the four pixel-waves of THEIR half
+      const int st_t = PP ? (tid & 255) : tid;
+      if (st_t < (PP ? BN : 2 * BN)) {
+        const int q = PP ? st_t / (BN / 2) : st_t / BN;
+        const int cl = PP ? grp * (BN / 2) + st_t % (BN / 2) : st_t - q * BN;
 #pragma unroll
         for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * BN + cl];   // fixed order: deterministic
         if (P.zdiv) {
@@ -1331,9 +1431,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #ifdef PDMA_STAMPS
   if (P.bn_mean && lane == 0) {
     unsigned long long* o = (unsigned long long*)P.bn_mean + ((size_t)blockIdx.x * 8 + wave) * 8;
-    o[0] = st_sum[0]; o[1] = st_sum[1]; o[2] = st_sum[2]; o[3] = st_sum[3]; o[4] = st_taps; o[5] = st_epi;
+    o[0] = st_sum[0]; o[1] = st_sum[1]; o[2] = st_sum[2]; o[3] = st_sum[3]; o[4] = st_taps; o[5] = PP ? st_rd : st_epi;
+    o[6] = st_b2;                                    // PP: wait at the barrier that ends COMPUTE
+    o[7] = ((__builtin_amdgcn_s_memtime() - st_t0) << 20) / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1);   // clock / 100 MHz, x 2^20
   }
 #endif
+  if constexpr (PP) { if (!grp) __builtin_amdgcn_s_barrier(); }        // pairs with the stagger barrier of waves 4-7
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy DMAs before the wave ends
 }
 
@@ -1341,6 +1444,10 @@ __global__ __launch_bounds__(512, 1) void conv3_pdma128_kernel(const IgemmParams
 __global__ __launch_bounds__(512, 1) void conv3_pdma64_kernel(const IgemmParams P) { conv3_pdma_body<64>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma128_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<128, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pp128_kernel(const IgemmParams P) { conv3_pdma_body<128, false, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pp64_kernel(const IgemmParams P) { conv3_pdma_body<64, false, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pp128_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<128, true, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pp64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, true>(P); }
 
 #ifdef PDMA_STAMPS
 void* g_pdma_debug = nullptr;
@@ -1354,8 +1461,15 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   P.tilesX = cdiv(P.W, C::TW);
   P.tilesY = cdiv(P.H, C::TH);
   const bool bnbwd = P.bn_y != nullptr;
-  auto kern = bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
-                    : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel);
+  // the ping-pong schedule wins where a work item is long (>= 8 chunks: +2 % at 512, +6 % at 1024 input channels) and
+  // loses where the epilogue -- run once per half, each exposed -- is a large part of an item (-10 % at 128 channels);
+  // UNET_PDMA_PP=0 / 1 force lock-step / ping-pong
+  const char ppv = unet_tuning().pdma_pp;
+  const bool pp = ppv == '1' || (ppv != '0' && BN == 128 && P.Ctot >= 512);
+  auto kern = pp ? (bnbwd ? (BN == 128 ? conv3_pp128_bnbwd_kernel : conv3_pp64_bnbwd_kernel)
+                          : (BN == 128 ? conv3_pp128_kernel : conv3_pp64_kernel))
+                 : (bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
+                          : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel));
   unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);

@@ -42,6 +42,7 @@ void read_tuning() {
   g_tuning.wgrad_impl = first("UNET_WGRAD_IMPL");
   g_tuning.ws_stats = first("UNET_WS_STATS");
   g_tuning.dgrad_bn = first("UNET_DGRAD_BN");
+  g_tuning.pdma_pp = first("UNET_PDMA_PP");
 }
 std::mutex g_lds_mu;
 std::vector<std::pair<int, const void*>> g_lds_done;

@@ -48,15 +48,23 @@ class FusedAdam(torch.optim.Optimizer):
                 ck[i] = r
             tab = {"sizes": sizes, "device": dev, "ptrs": None, "n_chunks": len(rows),
                    "chunks": torch.from_numpy(ck.view(np.uint8).copy()).to(dev),
-                   "host": torch.empty((len(sizes), 5), dtype=torch.int64).pin_memory(),
+                   # a ring of pinned staging buffers: one is rewritten only after the copy that last read it is done
+                   "host": [torch.empty((len(sizes), 5), dtype=torch.int64).pin_memory() for _ in range(4)],
+                   "host_done": [None] * 4, "host_i": 0,
                    "descs": torch.empty((len(sizes), 5), dtype=torch.int64, device=dev)}
             self._tables[gi] = tab
         if tab["ptrs"] != ptrs:
-            h = tab["host"]
-            for i, (p, st) in enumerate(zip(params, states)):
-                h[i, 0], h[i, 1] = p.data_ptr(), p.grad.data_ptr()
-                h[i, 2], h[i, 3], h[i, 4] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            i = tab["host_i"] = (tab["host_i"] + 1) % 4
+            h = tab["host"][i]
+            if tab["host_done"][i] is not None:
+                tab["host_done"][i].synchronize()
+            rows = h.numpy()
+            rows[:, :4] = np.asarray(ptrs, dtype=np.int64).reshape(-1, 4)
+            rows[:, 4] = sizes
             tab["descs"].copy_(h, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            tab["host_done"][i] = ev
             tab["ptrs"] = ptrs
         return tab
 

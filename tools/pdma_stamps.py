@@ -18,8 +18,6 @@ from tiaozhanbei_unet_amd import _lib as L, ops  # noqa: E402
 
 def main():
     n, ci, co, h, w = map(int, sys.argv[1:6])
-    pipe = sys.argv[6] if len(sys.argv) > 6 else "0"
-    os.environ["UNET_PDMA_PIPE"] = pipe
     dev = torch.device("cuda:0")
     lib = L.lib()
     handle = C.CDLL(L.LIB_PATH)
@@ -46,13 +44,19 @@ def main():
     us = e0.elapsed_time(e1) * 100
     d = dbg.view(256, 8, 8).cpu().double()
     taps = d[:, :, 4].clamp(min=1)
-    names = ["vmcnt wait", "barrier", "dma issue", "reads+mfma"]
-    print(f"conv fwd n={n} {ci}->{co} {h}x{w} pipe={pipe}: {us:.1f} us/launch (stamped build), taps/wave {float(taps.mean()):.0f}")
+    pp = os.environ.get("UNET_PDMA_PP", "0") in "12"
+    names = ["reads+dma issue", "vmcnt+lgkm wait", "barrier(L)", "mfma", "barrier(C)"] if pp else \
+        ["vmcnt wait", "barrier", "dma issue", "reads+mfma"]
+    cols = [0, 1, 2, 3, 6] if pp else [0, 1, 2, 3]
+    clock = float(d[:, :, 7].median()) / 2 ** 20 * 0.1
+    print(f"conv fwd n={n} {ci}->{co} {h}x{w} {'ping-pong' if pp else 'lock-step'}: {us:.1f} us/launch (stamped build), "
+          f"taps/wave {float(taps.mean()):.0f}, in-kernel clock {clock:.2f} GHz")
     for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
-        per = [float((d[:, sl, i] / taps[:, sl]).mean()) for i in range(4)]
+        per = [float((d[:, sl, i] / taps[:, sl]).mean()) for i in cols]
         tot = sum(per)
         print(f"  {grp}: " + "  ".join(f"{nm} {v:7.0f} ({100 * v / tot:4.1f}%)" for nm, v in zip(names, per)) +
-              f"   total/tap {tot:.0f} cyc;  epilogue/launch {float(d[:, sl, 5].mean()):.0f} cyc")
+              f"   total/tap {tot:.0f} cyc;  " + (f"of which fragment-read issue {float((d[:, sl, 5] / taps[:, sl]).mean()):.0f}/tap" if pp
+                                                 else f"epilogue/launch {float(d[:, sl, 5].mean()):.0f} cyc"))
 
 
 if __name__ == "__main__":
