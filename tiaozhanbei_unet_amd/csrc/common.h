@@ -47,6 +47,11 @@ struct ProfScope {
   ~ProfScope() { unet_prof_end(k, f, s, name); }
 };
 
+// the deep transposed convolutions as one LDS-DMA GEMM (convt_gemm.hip); mode 0 forward, 1 data gradient
+bool unet_internal_convt_gemm_ok(int mode, int dtype, int n, int h, int w, int c_in, int c_out);
+int32_t unet_internal_convt_gemm(int mode, int n, int h, int w, const void* a, const void* w_packed, const float* bias,
+                                 void* out, int c_in, int c_out, hipStream_t s);
+
 // deterministic per-channel sum of x[pixels][C] (bn.hip); ws is scratch
 int32_t unet_internal_colsum(int dtype, const void* x, int64_t pixels, int C, float* out, float* ws,
                               size_t ws_bytes, hipStream_t s);

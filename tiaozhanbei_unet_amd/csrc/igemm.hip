@@ -2470,6 +2470,8 @@ extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_
       return c_in == 128 ? launch_convt_ws<128>(T, (hipStream_t)stream) : launch_convt_ws<256>(T, (hipStream_t)stream);
     }
   }
+  if (unet_internal_convt_gemm_ok(0, dtype, n, h, w, c_in, c_out))     // deep levels: one LDS-DMA GEMM (convt_gemm.hip)
+    return unet_internal_convt_gemm(0, n, h, w, x, w_packed, bias, y, c_in, c_out, (hipStream_t)stream);
   IgemmParams P{};
   P.src[0] = DView{(const char*)x, c_in, h, w, 0, 0};
   P.dst[0] = DViewW{(char*)y, c_out, 2 * h, 2 * w, 0, 0};
@@ -2502,6 +2504,8 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
                          : launch_convt_dgrad_ws<128>(T, (hipStream_t)stream);
     }
   }
+  if (unet_internal_convt_gemm_ok(1, dtype, n, h, w, c_in, c_out))
+    return unet_internal_convt_gemm(1, n, h, w, dy, w_packed, nullptr, dx, c_in, c_out, (hipStream_t)stream);
   IgemmParams P{};
   P.src[0] = DView{(const char*)dy, c_out, 2 * h, 2 * w, 0, 0};
   P.dst[0] = DViewW{(char*)dx, c_in, h, w, 0, 0};
