@@ -1110,7 +1110,19 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #endif
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
   bool after_epilogue = false;
-  float stat_tot = 0.f;                           // block-mode BatchNorm partial of this thread's (statistic, channel)
+  // BatchNorm partial sums of this lane's outputs (4 channels x CT tiles, 2 statistics).  Block mode (P.zdiv: every
+  // block visits every channel tile): a layer of thousands of tiles has 256 partials to finalise -- the block keeps a
+  // running total per (statistic, channel) over its work items of one channel tile.  BN = 64 (DEFER): the per-lane sums
+  // themselves run on across those items and are reduced over lanes and waves ONCE, at the last of them (the 64 DPP adds
+  // + LDS exchange + barrier leave the per-item epilogue: +3 %); at BN = 128 the 32 extra live registers spill (-5 %),
+  // so there every item reduces and a thread carries the total.  Fixed order either way: deterministic.
+  constexpr bool DEFER = BN == 64;
+  float stat_tot = 0.f;
+  float bs[C::CT][4], bq[C::CT][4];
+#pragma unroll
+  for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
   for (int wk = logical; wk < total; wk += G) {
     const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
     const int n = tile / tiles_img, r = tile - n * tiles_img;
@@ -1243,11 +1255,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
                                                  D.p ? (int)dimg : 0, 0x00020000);
     }
-    float bs[C::CT][4], bq[C::CT][4];
+    if constexpr (!DEFER) {
 #pragma unroll
-    for (int ct = 0; ct < C::CT; ++ct)
+      for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+    }
     if constexpr (BNBWD) {
       // dgrad + ReLU mask + BatchNorm-backward sums of the producing layer.  dst[0] is dense and frame-sized, so the
       // store offset of a (pixel, tile pair) is also the offset of its 8 y values; y comes in with the same 16-byte
@@ -1375,49 +1388,52 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
     }
     if (P.stats) {
-#pragma unroll
-      for (int ct = 0; ct < C::CT; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bs[ct][j] = row16_sum(bs[ct][j]);
-          bq[ct][j] = row16_sum(bq[ct][j]);
-        }
-      float* red = reinterpret_cast<float*>(smem + C::RED_BASE);     // [4 pixel-waves][2][BN]
-      if (l15 == 0) {
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int cl = wco * (BN / 2) + ct * 16 + kb * 4 + j;
-            red[(wpx * 2 + 0) * BN + cl] = bs[ct][j];
-            red[(wpx * 2 + 1) * BN + cl] = bq[ct][j];
-          }
-      }
-      // LDS-only exchange: raw barrier (a __syncthreads() would also wait for the output stores)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      // P.zdiv != 0 (block mode, every block visits every channel tile): a thread keeps the running total of ITS
-      // (statistic, channel) over the block's work items of this channel tile and writes ONE partial per block --
-      // a layer of thousands of tiles then has 256 partials to finalise instead of thousands.  Otherwise one
-      // partial per tile.  Either way exactly one (possibly dropped) store per work item: static vmcnt counts.
+      // exactly one (possibly dropped) statistics store per work item: static vmcnt counts
       const bool flush = !P.zdiv || !has_next || (wk + G) / n_tiles != cot;
       const int part = P.zdiv ? logical : (n * P.tilesY + tyi) * P.tilesX + txi;
       float tsum = 0.f;
       unsigned so = OOB;
-      // PP: the barrier above is this half's own exchange (the other half is a barrier apart); a half owns BN/2
-      // channels outright, so its BN threads (statistic, channel) total the four pixel-waves of THEIR half
-      const int st_t = PP ? (tid & 255) : tid;
-      if (st_t < (PP ? BN : 2 * BN)) {
-        const int q = PP ? st_t / (BN / 2) : st_t / BN;
-        const int cl = PP ? grp * (BN / 2) + st_t % (BN / 2) : st_t - q * BN;
+      if (!DEFER || flush) {
 #pragma unroll
-        for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * BN + cl];   // fixed order: deterministic
-        if (P.zdiv) {
-          stat_tot += tsum;
-          tsum = stat_tot;
-          if (flush) stat_tot = 0.f;
+        for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bs[ct][j] = row16_sum(bs[ct][j]);
+            bq[ct][j] = row16_sum(bq[ct][j]);
+          }
+        float* red = reinterpret_cast<float*>(smem + C::RED_BASE);     // [4 pixel-waves][2][BN]
+        if (l15 == 0) {
+#pragma unroll
+          for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int cl = wco * (BN / 2) + ct * 16 + kb * 4 + j;
+              red[(wpx * 2 + 0) * BN + cl] = bs[ct][j];
+              red[(wpx * 2 + 1) * BN + cl] = bq[ct][j];
+            }
         }
-        if (flush) so = (unsigned)((((size_t)part * 2 + q) * P.Cout + co0 + cl) * 4);
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
+        // LDS-only exchange: raw barrier (a __syncthreads() would also wait for the output stores)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // PP: that barrier is this half's own exchange (the other half is a barrier apart); a half owns BN/2 channels
+        // outright, so its BN threads (statistic, channel) total the four pixel-waves of THEIR half
+        const int st_t = PP ? (tid & 255) : tid;
+        if (st_t < (PP ? BN : 2 * BN)) {
+          const int q = PP ? st_t / (BN / 2) : st_t / BN;
+          const int cl = PP ? grp * (BN / 2) + st_t % (BN / 2) : st_t - q * BN;
+#pragma unroll
+          for (int wp = 0; wp < 4; ++wp) tsum += red[(wp * 2 + q) * BN + cl];   // fixed order: deterministic
+          if (!DEFER && P.zdiv) {
+            stat_tot += tsum;
+            tsum = stat_tot;
+            if (flush) stat_tot = 0.f;
+          }
+          if (flush) so = (unsigned)((((size_t)part * 2 + q) * P.Cout + co0 + cl) * 4);
+        }
       }
       const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)P.stats, (short)0, (int)std::min<long long>((long long)n_tiles * 2 * P.Cout * 4, 0x7FFFFFFFLL), 0x00020000);

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("h", type=int); ap.add_argument("w", type=int)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--op", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--op", default="fwd", choices=["fwd", "fwdstats", "dgrad", "wgrad"])
     ap.add_argument("--ab", default="", help="comma list of values of --abvar to A/B interleaved in one process")
     ap.add_argument("--abvar", default="UNET_CONV_IMPL")
     ap.add_argument("--acc", type=int, default=0, help="accumulate bit mask of the conv dgrad (dst += result)")
@@ -65,6 +65,12 @@ def main():
         if a.op == "fwd":
             run = lambda: L.check(lib.unet_conv3x3(ops._DT[dt], n, h, w, V([(x, 0, 0), None]), p(wp), co,
                                                    V([(y, 0, 0), None]), co, 0, 0, st), "fwd")
+        elif a.op == "fwdstats":                      # forward + BatchNorm partial sums in the epilogue (training)
+            cap = lib.unet_conv3x3_stats_max_parts(n, h, w)
+            part = torch.empty(cap * 2 * co, device=dev)
+            nparts = C.c_int32(0)
+            run = lambda: L.check(lib.unet_conv3x3_stats(ops._DT[dt], n, h, w, V([(x, 0, 0), None]), p(wp), co, p(y),
+                                                         p(part), C.byref(nparts), st), "fwd+stats")
         elif a.op == "dgrad":
             run = lambda: L.check(lib.unet_conv3x3(ops._DT[dt], n, h, w, V([(gy, 0, 0), None]), p(wpd), ci,
                                                    V([(dx, 0, 0), None]), ci, a.acc, 1, st), "dgrad")
@@ -113,7 +119,7 @@ def main():
         for v in variants:
             os.environ[a.abvar] = v
             lib.unet_tuning_reload()
-            tgt = {"fwd": y, "dgrad": dx, "wgrad": dw}[a.op]
+            tgt = {"fwd": y, "fwdstats": y, "dgrad": dx, "wgrad": dw}[a.op]
             tgt.zero_()
             run()
             torch.cuda.synchronize()
