@@ -1542,13 +1542,20 @@ struct CfgWS {
 // sums next to its 144 weight registers, so every tile's 2 x 16 per-lane values are reduced over the 16 lanes of a DPP
 // row at once (4 VALU adds each), the four row leaders leave them in an LDS slot, and 128 threads keep the block's
 // running total of their (statistic, channel) -- one ordered partial per block: deterministic.
-template <bool ACC, int STATS = 0>
+// ST ("stagger"): a tile is two phases with a barrier after each -- M: the DMA issue of the tile two ahead + the 72
+// MFMAs (+ the counted wait for the NEXT tile's patch), E: the tile's epilogue (pack, statistics, stores) + the next
+// tile's output geometry -- and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave's MFMA phase
+// covers its partner's VALU/store phase (in lock-step all eight did their epilogues together, then fought over the
+// matrix pipe: 40 % MFMA busy).  Waves 0-3 own output channels 0-31, waves 4-7 channels 32-63 (a half's statistics
+// stay inside the half).
+template <bool ACC, int STATS = 0, bool ST = false>
 __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, int tiles_per_block) {
   using C = CfgWS;
   static_assert(!(ACC && STATS), "the gradient fan-in form carries no statistics");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave & 1, wpx = wave >> 1;
+  const int grp = wave >> 2;
+  const int wco = ST ? grp : (wave & 1), wpx = ST ? (wave & 3) : (wave >> 1);
   const int l31 = lane & 31, hh = lane >> 5;
   const int nCg = P.Cout / C::ROWS;
   // channel groups of one tile range sit on the SAME XCD (b % 8) in adjacent dispatch slots, so the
@@ -1598,33 +1605,59 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   // LDS-DMA staging (buffer_load_dwordx4 ... lds): the padded LDS image is filled LINEARLY, 1 KiB per wave
   // instruction; pad pieces and out-of-image halo pixels use an out-of-range voffset and land as zeros.
   // No staging registers: whole patches are in flight while this tile computes.
-  int a_code[C::NDMA];            // hy | hx << 8 | part << 16   (-1: pad piece)
+  // per lane and instruction, constant over the tiles, two to a register: hy | hx << 5 | piece << 10 | 1 << 14 (0 = pad
+  // piece).  A tile then costs a dozen VALU instructions per DMA (the tile's own origin is scalar) where the lane
+  // geometry used to be divided out and multiplied up per tile (~300 per tile, fighting the partner wave's epilogue for
+  // the SIMD's vector issue: the stamps showed them taking as long as the tile's 72 MFMAs).
+  unsigned a_pk[(C::NDMA + 1) / 2];
 #pragma unroll
   for (int j = 0; j < C::NDMA; ++j) {
     const int q = (j * C::NWAVE + wave) * 64 + lane;              // instruction index j*NWAVE + wave
     const int hy = q / (C::RS / 16), rem = q - hy * (C::RS / 16);
     const int hx = rem / 9, part = rem - hx * 9;
-    a_code[j] = (hy < C::HH && hx < C::HW && part < 8) ? (hy | (hx << 8) | (part << 16)) : -1;
+    const unsigned code = (hy < C::HH && hx < C::HW && part < 8) ? (unsigned)(hy | (hx << 5) | (part << 10) | (1 << 14)) : 0u;
+    if (j & 1) a_pk[j >> 1] |= code << 16;
+    else a_pk[j >> 1] = code;
   }
   const unsigned img_bytes = (unsigned)S.H * S.W * S.C * 2u;
   typedef __attribute__((address_space(3))) void lds_void;
 
-  auto dma_a = [&](int tile, int buf) {
-    const int n = tile / tiles_img, r = tile - n * tiles_img;
-    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(S.p + (size_t)n * img_bytes), (short)0, (int)img_bytes, 0x00020000);
+  // tile coordinates advance by increments (no per-tile divisions): one iterator per consumer
+  struct TileIt { int n, ty, tx; };
+  auto tile_at = [&](int tile) {
+    TileIt it;
+    it.n = tile / tiles_img;
+    const int r = tile - it.n * tiles_img;
+    it.ty = r / P.tilesX;
+    it.tx = r - it.ty * P.tilesX;
+    return it;
+  };
+  auto tile_next = [&](TileIt& it) {
+    if (++it.tx == P.tilesX) {
+      it.tx = 0;
+      if (++it.ty == P.tilesY) { it.ty = 0; ++it.n; }
+    }
+  };
+  TileIt dma_it = tile_at(t_begin), geo_it = dma_it;
+
+  auto dma_a = [&](int buf, bool live) {         // the patch of the tile at dma_it (then advance); dead = to the dummy KiB
+    const int ym1 = dma_it.ty * C::WTH - 1, xm1 = dma_it.tx * C::WTW - 1;
+    const unsigned base = (unsigned)((ym1 * S.W + xm1) * S.C * 2);      // (may wrap below zero: only valid sums are used)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(S.p + (size_t)(live ? dma_it.n : 0) * img_bytes), (short)0, (int)img_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < C::NDMA; ++j) {
-      const int code = a_code[j];
-      const int hy = code & 255, hx = (code >> 8) & 255, part = (code >> 16) & 255;
-      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-      const bool ok = code >= 0 && y >= 0 && y < S.H && x >= 0 && x < S.W;
-      const unsigned vo = ok ? (unsigned)((y * S.W + x) * S.C * 2 + part * 16) : OOB;
+      unsigned code = (a_pk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+      asm volatile("" : "+v"(code));               // decode per tile: hoisted out of the loop it costs 21 live registers
+      const int hy = code & 31, hx = (code >> 5) & 31, part = (code >> 10) & 15;
+      const unsigned y = (unsigned)(ym1 + hy), x = (unsigned)(xm1 + hx);
+      const bool ok = live && (code >> 14) && y < (unsigned)S.H && x < (unsigned)S.W;
+      const unsigned vo = ok ? base + (unsigned)((hy * S.W + hx) * S.C * 2 + part * 16) : OOB;
       const int idx = j * C::NWAVE + wave;                          // wave-uniform
-      char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
+      char* dst = (live && idx < C::NINSTR) ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, 0, 0, 0);
     }
+    tile_next(dma_it);
   };
 
   // ring of NBUF patches: tile k computes from slot k % NBUF while the DMAs of tiles k+1, k+2 are in flight.
@@ -1639,34 +1672,18 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
   // leaves those DMAs in flight); by the next tile's wait they are long complete but still count as issued-after
   constexpr int NY = STATS == 2 ? 2 * C::PXT : 0;
   static_assert(2 * NST + C::NDMA + NY <= 63, "vmcnt range");
-#pragma unroll
-  for (int d = 0; d < C::NBUF - 1; ++d)
-    if (t_begin + d < t_end) dma_a(t_begin + d, d);
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int k = tile - t_begin;
-    const int cur = k % C::NBUF;
-    const bool next_in_flight = tile + 1 < t_end;
-    if (k >= 2) {
-      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST + C::NDMA + NY) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
-    } else if (k == 1) {
-      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + C::NDMA + NY) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-    } else {
-      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (STATS && k >= 1 && tid < 128) {            // the previous tile's slots -> this thread's running total
-      const float* rp = red + ((k - 1) & 1) * 1024 + (tid >> 6) * 512 + (tid & 63);
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) stat_tot += rp[sl * 64];
-    }
-
-    // ---- output geometry of this tile (buffer stores: an OOB offset = dropped, so the op count is static)
-    const int n = tile / tiles_img, r = tile - n * tiles_img;
-    const int ty0 = (r / P.tilesX) * C::WTH, tx0 = (r % P.tilesX) * C::WTW;
-    __amdgpu_buffer_rsrc_t drs[2];
+  // ---- output geometry of a tile (buffer stores: an OOB offset = dropped, so the op count is static)
+  // A lane of the 32x32 accumulator owns rows 8g+4hh..+3 of pixel l31; v_permlane32_swap trades the g-odd run
+  // of the lower half-wave for the g-even run of the upper one, so every lane ends up with 8 CONSECUTIVE
+  // channels (rows 16gp + 8hh ..+7) and writes 16 bytes: half as many store instructions, 32-byte segments.
+  __amdgpu_buffer_rsrc_t drs[2];
+  unsigned ovo[C::PXT][2][NVIEW];
+  int n_img = 0;
+  auto geometry = [&]() {                        // of the tile at geo_it (then advance)
+    const int n = geo_it.n;
+    const int ty0 = geo_it.ty * C::WTH, tx0 = geo_it.tx * C::WTW;
+    tile_next(geo_it);
+    n_img = n;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const DViewW D = P.dst[q];
@@ -1674,10 +1691,6 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
                                                  D.p ? (int)dimg : 0, 0x00020000);
     }
-    // A lane of the 32x32 accumulator owns rows 8g+4hh..+3 of pixel l31; v_permlane32_swap trades the g-odd run
-    // of the lower half-wave for the g-even run of the upper one, so every lane ends up with 8 CONSECUTIVE
-    // channels (rows 16gp + 8hh ..+7) and writes 16 bytes: half as many store instructions, 32-byte segments.
-    unsigned ovo[C::PXT][2][NVIEW];
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
       const int m = wpx * (32 * C::PXT) + pt * 32 + l31;
@@ -1697,6 +1710,56 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
         }
       }
     }
+  };
+  // statistics: the slots of tile kk (this half's four waves, or all eight in lock-step) -> the thread's running total
+  const int st_u = ST ? (tid & 255) : tid;
+  const bool st_on = STATS && st_u < (ST ? 64 : 128);
+  const int st_q = ST ? (st_u >> 5) : (st_u >> 6), st_c = ST ? grp * 32 + (st_u & 31) : (st_u & 63);
+  auto take_slots = [&](int kk) {
+    if (st_on) {
+      const float* rp = red + (kk & 1) * 1024 + st_q * 512 + st_c;
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) stat_tot += rp[sl * 64];
+    }
+  };
+
+#pragma unroll
+  for (int d = 0; d < C::NBUF - 1; ++d)
+    if (ST || t_begin + d < t_end) dma_a(d, t_begin + d < t_end);
+  if constexpr (ST) {
+    geometry();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");          // the first patch; the second one flies
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();                                  // the stagger
+  }
+#ifdef PDMA_STAMPS
+  unsigned long long ws_st[5] = {0, 0, 0, 0, 0}, ws_prev = __builtin_amdgcn_s_memtime(), ws_dma_sum = 0;
+  const unsigned long long ws_t0 = ws_prev, ws_r0 = __builtin_amdgcn_s_memrealtime();
+#define WS_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ws_st[i] += t_ - ws_prev; ws_prev = t_; }
+#else
+#define WS_STAMP(i)
+#endif
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int k = tile - t_begin;
+    const int cur = k % C::NBUF;
+    const bool next_in_flight = tile + 1 < t_end;
+    if constexpr (!ST) {
+    if (k >= 2) {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST + C::NDMA + NY) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
+    } else if (k == 1) {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + C::NDMA + NY) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    } else {
+      if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (k >= 1) take_slots(k - 1);                 // the previous tile's slots -> this thread's running total
+    geometry();
+    }
+    const int n = n_img;
+    (void)n;
     // STATS == 2: this tile's y values (same offsets as the stores: dst[0] is dense and frame-sized) are requested
     // FIRST, then the DMAs of the tile two ahead
     u32x4 yv[STATS == 2 ? C::PXT : 1][2];
@@ -1709,7 +1772,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) yv[pt][gp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ovo[pt][gp][0], 0, 0);
     }
-    if (tile + C::NBUF - 1 < t_end) dma_a(tile + C::NBUF - 1, (k + C::NBUF - 1) % C::NBUF);
+    if (ST || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
     // gradient fan-in (ACC): the old values are fetched NOW, behind the tile's 72 MFMAs (one load per output
     // run, from whichever view owns it and has its accumulate bit set; everything else reads as 0)
     u32x4 oldv[ACC ? C::PXT : 1][2];
@@ -1734,12 +1797,19 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     const char* pb = smem + cur * C::A_BYTES;
     // 36 (tap, 16-channel group) steps of PXT MFMAs; the pixel fragments of step i+2 are requested before the MFMAs
     // of step i and pinned there (left alone, hipcc requests them one MFMA ahead: the LDS round trip showed)
-    constexpr int DEPTH = STATS == 2 ? 1 : 2;      // (the masked-gradient form needs the registers for its y values)
+#ifndef WS_DEPTH
+#define WS_DEPTH 2
+#endif
+    constexpr int DEPTH = STATS == 2 ? 1 : WS_DEPTH;      // (the masked-gradient form needs the registers for its y values)
     auto frag = [&](int i, int pt) {
       const int tap = i >> 2, kg = i & 3;
       return *reinterpret_cast<const bf16x8*>(pb + boff[pt] + (tap / 3) * C::RS + (tap % 3) * C::PSTR + kg * 32);
     };
     bf16x8 ring[DEPTH + 1][C::PXT];
+#ifdef PDMA_STAMPS
+    unsigned long long ws_dma = 0;
+    if (ST) ws_dma = __builtin_amdgcn_s_memtime() - ws_prev;
+#endif
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
 #pragma unroll
@@ -1757,6 +1827,21 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (ST) {
+#ifdef PDMA_STAMPS
+      ws_dma_sum += ws_dma;
+#endif
+      // end of the M phase: the NEXT tile's patch (issued one tile ago) has landed; younger than it: the previous
+      // tile's stores, this tile's y loads and the patch just issued
+      WS_STAMP(0)
+      if (k >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + NY + C::NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NY + C::NDMA) : "memory");
+      WS_STAMP(1)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      WS_STAMP(2)
+    }
     // ---- epilogue for this tile: exactly NST buffer stores per wave (OOB offset = dropped).  Per 16-channel group gp
     // the two 4-row runs of a lane (t = 0: rows 16gp+4hh.., t = 1: +8) are finished one after the other so that only
     // one run's coefficients and sums are live (the statistics forms sit at the 256-register limit).
@@ -1847,19 +1932,38 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
         for (int q = 0; q < NVIEW; ++q) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][gp][q], 0, 0);
       }
     }
-  }
-  if constexpr (STATS != 0) {
-    // the last tile's slots, then ONE partial per block
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (tid < 128) {
-      const int kl = t_end - 1 - t_begin;
-      const float* rp = red + (kl & 1) * 1024 + (tid >> 6) * 512 + (tid & 63);
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) stat_tot += rp[sl * 64];
-      P.stats[((size_t)tr * 2 + (tid >> 6)) * P.Cout + cg * C::ROWS + (tid & 63)] = stat_tot;
+    if constexpr (ST) {
+      // rest of the E phase: the previous tile's slots (written a barrier pair ago), the next tile's geometry
+      if (k >= 1) take_slots(k - 1);
+      if (next_in_flight) geometry();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this tile's slot writes, before the half's barrier
+      WS_STAMP(3)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      WS_STAMP(4)
     }
   }
+#ifdef PDMA_STAMPS
+  if (ST && STATS != 2 && P.bn_mean && lane == 0) {
+    unsigned long long* o = (unsigned long long*)P.bn_mean + ((size_t)(blockIdx.x & 255) * 8 + wave) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = ws_st[i];
+    o[5] = (unsigned long long)(t_end - t_begin);
+    o[7] = ws_dma_sum;
+    o[6] = ((__builtin_amdgcn_s_memtime() - ws_t0) << 20) / (__builtin_amdgcn_s_memrealtime() - ws_r0 + 1);
+  }
+#endif
+  if constexpr (ST) { if (!grp) __builtin_amdgcn_s_barrier(); }    // pairs with the stagger barrier of waves 4-7
+  if constexpr (STATS != 0) {
+    // the last tile's slots, then ONE partial per block
+    if constexpr (!ST) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    take_slots(t_end - 1 - t_begin);
+    if (st_on) P.stats[((size_t)tr * 2 + st_q) * P.Cout + cg * C::ROWS + st_c] = stat_tot;
+  }
+  if constexpr (ST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMAs before the wave ends
 }
 
 int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
@@ -1869,8 +1973,17 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
                         P.dst[0].oy == 0 && P.dst[0].ox == 0 && P.dst[0].H == P.H && P.dst[0].W == P.W;
   const int mode = P.bn_y ? 2 : ((P.stats && stats_ok) ? 1 : 0);
   UNET_REQUIRE(mode != 2 || stats_ok, UNET_ERR_UNSUPPORTED, "conv3_ws: fused BatchNorm backward needs one dense destination");
-  auto kern = P.accumulate ? conv3_ws_kernel<true, 0>
-                           : (mode == 2 ? conv3_ws_kernel<false, 2> : (mode == 1 ? conv3_ws_kernel<false, 1> : conv3_ws_kernel<false, 0>));
+  // the staggered schedule pays where the epilogue is long (the statistics forms: +3.5 % on 64 -> 64 @256x256) and costs
+  // 20 % where it is short (plain forward / data gradient: the DMA burst of a half then lands inside the other half's
+  // MFMA phase); UNET_WS_ST=0 / 1 force lock-step / staggered, 3 = staggered for the BatchNorm-backward form too
+  const char stv = unet_tuning().ws_st;
+  const bool st = stv == '1' || (stv != '0' && (mode == 1 || (mode == 2 && stv == '3')));
+  auto kern = st ? (P.accumulate ? conv3_ws_kernel<true, 0, true>
+                                 : (mode == 2 ? conv3_ws_kernel<false, 2, true>
+                                              : (mode == 1 ? conv3_ws_kernel<false, 1, true> : conv3_ws_kernel<false, 0, true>)))
+                 : (P.accumulate ? conv3_ws_kernel<true, 0>
+                                 : (mode == 2 ? conv3_ws_kernel<false, 2>
+                                              : (mode == 1 ? conv3_ws_kernel<false, 1> : conv3_ws_kernel<false, 0>)));
   P.tilesX = cdiv(P.W, C::WTW);
   P.tilesY = cdiv(P.H, C::WTH);
   const long long tiles = (long long)P.N * P.tilesY * P.tilesX;
@@ -1882,6 +1995,9 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   if (mode == 0) P.stats = nullptr;               // (statistics, if wanted, by the caller's streaming pass)
   if (stat_parts) *stat_parts = mode ? (int)ranges8 : 0;          // one ordered partial per tile range
+#ifdef PDMA_STAMPS
+  if (mode != 2) P.bn_mean = (const float*)g_pdma_debug;
+#endif
   ProfScope prof(kclass, flops, s, mode == 2 ? "conv3_ws_bnbwd_kernel" : "conv3_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P, tpb);
   return unet_check_launch("conv3_ws_kernel");
