@@ -225,10 +225,14 @@ def main():
                 try:
                     pmc = json.load(open(PMC_FILE))["kernels"]
                     key = name.split(" ")[0]
-                    if key in pmc:
-                        traffic = pmc[key]["traffic_bytes_per_launch"]
+                    # a bracket name covers the lock-step (pdma) and ping-pong (pp) instantiations of one kernel body
+                    fam = [k for k in pmc if k.split("<")[0] in (key, key.replace("_pdma", "_pp"))]
+                    if fam:
+                        nl = sum(pmc[k]["launches"] for k in fam)
+                        traffic = int(sum(pmc[k]["traffic_bytes_per_launch"] * pmc[k]["launches"] for k in fam) / nl)
                         traffic_note = ("bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from the rocprofv3 --pmc passes of "
-                                        "this command (profiles/r02_pmc_traffic.json; default config only)")
+                                        "this command (profiles/r02_pmc_traffic.json; default config only; launch-weighted "
+                                        "over " + ", ".join(sorted(fam)) + ")")
                 except (OSError, ValueError, KeyError):
                     pass
                 # algorithmic bytes of the layers that kernel serves (>= 128 input channels, forward + data gradient)

@@ -264,7 +264,9 @@ def test_conv3x3_concat_and_centre_pad_views(hip, dtype, geom):
                                   # widths that are multiples of 32: the streaming weight-gradient kernels
                                   (2, 128, 64, 8, 32), (1, 256, 128, 4, 64), (3, 128, 64, 3, 32), (2, 256, 128, 16, 32),
                                   # the deep levels (bf16: convt_gemm_kernel, 256 x 256 tiles; ragged and several pixel tiles)
-                                  (2, 512, 256, 8, 8), (3, 1024, 512, 5, 7), (4, 512, 256, 16, 16)], ids=str)
+                                  (2, 512, 256, 8, 8), (3, 1024, 512, 5, 7), (4, 512, 256, 16, 16),
+                                  # ... and their streaming weight gradient (width 16: a tile = two image rows; width 32)
+                                  (2, 1024, 512, 16, 16), (1, 512, 256, 4, 32)], ids=str)
 def test_convt2x2(hip, dtype, case):
     L, ops = hip
     n, ci, co, h, w = case

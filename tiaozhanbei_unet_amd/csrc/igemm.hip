@@ -1502,6 +1502,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
 #ifdef PDMA_STAMPS
   if (!bnbwd) P.bn_mean = (const float*)g_pdma_debug;
 #endif
+  // (one bracket name per body: the lock-step and ping-pong instantiations of conv3_pdma_body<BN> are one kernel family)
   ProfScope prof(kclass, flops, s, bnbwd ? (BN == 128 ? "conv3_pdma128_bnbwd_kernel" : "conv3_pdma64_bnbwd_kernel")
                                           : (BN == 128 ? "conv3_pdma128_kernel" : "conv3_pdma64_kernel"));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);

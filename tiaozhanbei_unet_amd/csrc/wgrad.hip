@@ -633,10 +633,14 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_ws_kernel(const CtwParams 
       (void*)P.x, (short)0, (int)std::min<long long>(x_total, 0x7FFFFFFFLL), 0x00020000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)P.dy, (short)0, (int)std::min<long long>(dy_total, 0x7FFFFFFFLL), 0x00020000);
-  const int tiles_row = P.W / C::TP;             // W % 32 == 0: a tile lies inside one image row
+  // W % 32 == 0: a tile lies inside one image row; W == 16 (the deepest level): a tile is two whole rows of one image
+  // (H is even there), a lane's pixel row r sits in tile row r >> 4
+  const bool narrow = P.W < C::TP;
+  const int tiles_row = narrow ? 1 : P.W / C::TP;
 
   auto dma = [&](int tile, int buf) {
-    const int ry = tile / tiles_row, x0 = (tile - ry * tiles_row) * C::TP;   // ry = n*H + y (wave-uniform)
+    const int ry = narrow ? tile * 2 : tile / tiles_row;                     // ry = n*H + y (wave-uniform)
+    const int x0 = narrow ? 0 : (tile - ry * tiles_row) * C::TP;
     const int n = ry / P.H, y = ry - n * P.H;
     const long long xpix0 = (long long)ry * P.W + x0;
     const long long dpix0 = ((long long)n * 2 * P.H + 2 * y) * (2 * P.W) + 2 * x0;
@@ -649,7 +653,9 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_ws_kernel(const CtwParams 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)dst, 16, vo, 0, 0, 0);
       } else {
         const int z = d_off[j] & 255, co = d_off[j] >> 8;
-        const long long dp = dpix0 + (long long)(z >> 1) * (2 * P.W) + 2 * d_row[j] + (z & 1);
+        // (narrow: pixel row r = 16 * dy + x -> two output rows further down per dy)
+        const int rr = narrow ? (d_row[j] >> 4) * (4 * P.W) + 2 * (d_row[j] & 15) : 2 * d_row[j];
+        const long long dp = dpix0 + (long long)(z >> 1) * (2 * P.W) + rr + (z & 1);
         const unsigned vo = (unsigned)(dp * (C::COUT * 2) + co * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)dst, 16, vo, 0, 0, 0);
       }
@@ -770,7 +776,9 @@ int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w
 
 inline bool convt_wgrad_ws_ok(int dtype, int n, int h, int w, int c_in, int c_out) {
   const long long xb = (long long)n * h * w * c_in * 2;
-  return dtype == UNET_BF16 && (c_in == 128 || c_in == 256) && c_out * 2 == c_in && w % 32 == 0 &&
+  const bool deep = (c_in == 512 || c_in == 1024) && unet_tuning().convt_impl != '3';   // (3: deep levels generic)
+  return dtype == UNET_BF16 && (c_in == 128 || c_in == 256 || deep) && c_out * 2 == c_in &&
+         (w % 32 == 0 || (w == 16 && h % 2 == 0)) && ((long long)n * h * w) % 32 == 0 &&
          2 * xb < 0x7FFFFFFFLL && unet_tuning().convt_impl != '0';      // (UNET_CONVT_IMPL=0: generic kernels)
 }
 inline size_t convt_wgrad_ws_bytes(int n, int h, int w, int c_in) {
@@ -797,8 +805,11 @@ extern "C" int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int3
   UNET_REQUIRE(c_in % 64 == 0 && c_out % 64 == 0, UNET_ERR_UNSUPPORTED,
                "unet_convt2x2_wgrad: channels %d -> %d must be multiples of 64", c_in, c_out);
   if (convt_wgrad_ws_ok(dtype, n, h, w, c_in, c_out)) {
-    return c_in == 128 ? launch_convt_wgrad_ws<128>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, (hipStream_t)stream)
-                       : launch_convt_wgrad_ws<256>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (c_in == 128) return launch_convt_wgrad_ws<128>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, st);
+    if (c_in == 256) return launch_convt_wgrad_ws<256>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, st);
+    if (c_in == 512) return launch_convt_wgrad_ws<512>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, st);
+    return launch_convt_wgrad_ws<1024>(x, dy, n, h, w, dw, db, workspace, workspace_bytes, st);
   }
   const Plan pl = make_plan<4>(n, h, w, c_in, c_out);
   UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_convt2x2_wgrad: workspace %zu < %zu",
