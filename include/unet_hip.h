@@ -179,6 +179,19 @@ int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, const 
 /* dx from dy (dy is the [n][2h][2w][c_out] gradient); w_packed = UNET_PACK_CONVT_DGRAD. */
 int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy,
                             int32_t c_out, const void* w_packed, void* dx, int32_t c_in, void* stream);
+
+/* The same data gradient when the transposed convolution's input is the activation of a conv-BatchNorm-ReLU layer with
+ * no other consumer (the DoubleConv in front of an Up block: src/model.py:14-19 -> :51, autograd of Up.forward :55):
+ * the epilogue applies that layer's ReLU mask (from its raw conv output y_prev and scale/shift) and reduces the
+ * BatchNorm-backward sums, as unet_conv3x3_dgrad_bnrelu does for a 3x3 consumer.  dz = masked gradient
+ * [n][h][w][c_in]; partial = [unet_convt2x2_dgrad_bnrelu_max_parts()][2][c_in] floats (sum dz, sum dz*(y-mean)),
+ * *n_parts rows written; finish with unet_bn_bwd_premasked. */
+int32_t unet_convt2x2_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+size_t unet_convt2x2_dgrad_bnrelu_max_parts(void);
+int32_t unet_convt2x2_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy, int32_t c_out,
+                                   const void* w_packed, const void* y_prev, const float* bn_scale, const float* bn_shift,
+                                   const float* bn_mean, void* dz, int32_t c_in, float* partial, int32_t* n_parts,
+                                   void* stream);
 size_t unet_convt2x2_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
 /* dw[ci][co][2][2], db[co] in fp32. */
 int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* x, int32_t c_in,

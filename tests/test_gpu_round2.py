@@ -421,3 +421,48 @@ def test_pool_fused_with_batchnorm_relu(precision, shape, use_skip):
     assert l2rel(xd.grad, xr.grad) < gt, l2rel(xd.grad, xr.grad)
     for k, prm in m.double_conv.named_parameters():
         assert l2rel(prm.grad, dict(ref.named_parameters())[k].grad) < gt, (k, l2rel(prm.grad, dict(ref.named_parameters())[k].grad))
+
+
+@pytest.mark.parametrize("widths,n,h", [((256, 128, 64), 2, 8), ((256, 128, 64), 3, 5), ((512, 256, 128), 2, 8)], ids=str)
+def test_convt_dgrad_fused_with_batchnorm_backward(widths, n, h, monkeypatch):
+    """Up -> Up chain in bf16 training mode: the data gradient of the second block's transposed convolution applies the
+    first block's last ReLU mask and reduces its BatchNorm-backward sums (unet_convt2x2_dgrad_bnrelu +
+    unet_bn_bwd_premasked).  Checked against the same chain with the fusion switched off (identical masked gradient,
+    sums in another order) and, through it, against the torch reference the unfused path is tested with."""
+    import tiaozhanbei_unet_amd as P
+    from tiaozhanbei_unet_amd import ops
+    c0, c1, c2 = widths
+    torch.manual_seed(5)
+    up_a = P.Up(c0, c1, bilinear=False, precision="bf16").to(DEV).train()
+    up_b = P.Up(c1, c2, bilinear=False, precision="bf16").to(DEV).train()
+    x5 = torch.randn(n, c0, h, h, device=DEV)
+    x4 = torch.randn(n, c0 // 2, 2 * h, 2 * h, device=DEV)
+    x3 = torch.randn(n, c1 // 2, 4 * h, 4 * h, device=DEV)
+    gout = torch.randn(n, c2, 4 * h, 4 * h, device=DEV)
+    params = list(up_a.parameters()) + list(up_b.parameters())
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_BN_CONVT", fused)
+        for p_ in params:
+            p_.grad = None
+        xa = x5.clone().requires_grad_(True)
+        link = ops.BnLink()
+        with P.model._BatchedCounters():
+            y = up_a(xa, x4, out_link=link)
+            out = up_b(y, x3, in_link=link)
+        out.float().backward(gout)
+        torch.cuda.synchronize()
+        return out.detach().float().clone(), xa.grad.clone(), [p_.grad.clone() for p_ in params]
+
+    out1, gx1, g1 = run(True)
+    # offered for 128 -> 64 transposed convolutions (up4); elsewhere the link is simply not taken and both runs coincide
+    assert bool(ops.L.lib().unet_convt2x2_dgrad_bnrelu_supported(ops.L.UNET_BF16, n, 2 * h, 2 * h, c1, c1 // 2)) == (c1 == 128)
+    out0, gx0, g0 = run(False)
+    assert torch.equal(out0, out1)
+    names = [k for k, _ in list(up_a.named_parameters())] + ["b." + k for k, _ in up_b.named_parameters()]
+    for name, a, b in zip(names, g1, g0):
+        rel = float((a - b).norm() / (b.norm() + 1e-12))
+        # gamma/beta gradients of the linked BatchNorm come straight from the fused sums; everything upstream of it sees
+        # a dy that may differ by one bf16 rounding where the sums differ in the last bit
+        assert rel < (2e-4 if name == "conv.double_conv.4.weight" or name == "conv.double_conv.4.bias" else 2e-2), (name, rel)
+    assert float((gx1 - gx0).norm() / gx0.norm()) < 2e-2

@@ -53,6 +53,9 @@ SIGNATURES = {
     "unet_conv3x3_first_wgrad_workspace": (_z, [_i, _i, _i]),
     "unet_conv3x3_first_wgrad": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
     "unet_bn_finalize_partials": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
+    "unet_convt2x2_dgrad_bnrelu_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_convt2x2_dgrad_bnrelu_max_parts": (_z, []),
+    "unet_convt2x2_dgrad_bnrelu": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "unet_conv3x3_dgrad_bnrelu_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_conv3x3_dgrad_bnrelu": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "unet_conv3x3_wgrad_workspace": (_z, [_i, _i, _i, _i, _i]),

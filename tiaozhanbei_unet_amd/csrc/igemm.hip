@@ -2032,6 +2032,10 @@ struct ConvTParams {
   const char* x; char* y; const char* w; const float* bias;
   int N, H, W, Cout;      // input spatial dims; output is [N][2H][2W][Cout]
   int tiles, tiles_per_block;
+  // data gradient fused with the ReLU mask and the BatchNorm-backward sums of the layer that produced the transposed
+  // convolution's input (convt_dgrad_ws_kernel<COUT, true>): that layer's raw conv output, its coefficients, the
+  // partial sums [blocks][2][CIN]
+  const char* bn_y; const float* bn_scale; const float* bn_shift; const float* bn_mean; float* stats;
 };
 
 template <int CIN>
@@ -2226,7 +2230,8 @@ struct CfgTD {
   static constexpr int NDMA = (NINSTR + NWAVE - 1) / NWAVE;
   static constexpr int A_BYTES = NINSTR * 1024;
   static constexpr int NBUF = 2;
-  static constexpr int LDS = NBUF * A_BYTES + 1024;
+  static constexpr int CT_BASE = NBUF * A_BYTES + 1024;         // BNB: [scale | shift | mean][CIN], then the wave exchange
+  static constexpr int LDS = CT_BASE + 3 * CIN * 4 + 2 * 2 * CIN * 4;
   static constexpr int RW = CIN / 32;                           // waves along rows (4 or 8)
   static constexpr int PW = NWAVE / RW;                         // waves along pixels (2 or 1)
   static constexpr int PXT = TP / PW / 32;                      // MFMA pixel tiles per wave (2)
@@ -2234,7 +2239,11 @@ struct CfgTD {
   static constexpr int NST = 2 * PXT;
 };
 
-template <int COUT>
+// BNB: the gradient this kernel produces is d loss / d a of a conv-BatchNorm-ReLU layer (the DoubleConv in front of the
+// Up block, src/model.py:14-19 -> :51): the epilogue loads that layer's raw output y with the store offsets, applies the
+// ReLU mask relu'(scale*y+shift), stores dz and keeps per-lane running sums of dz and dz*(y-mean) over the block's
+// tiles; one cross-lane / cross-wave reduction at the end -> one ordered partial per block (deterministic).
+template <int COUT, bool BNB = false>
 __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParams P) {
   using C = CfgTD<COUT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2244,7 +2253,23 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
   const int row_lane = wr * 32 + l31;
   const int t_begin = blockIdx.x * P.tiles_per_block;
   const int t_end = min(t_begin + P.tiles_per_block, P.tiles);
-  if (t_begin >= t_end) return;
+  if (t_begin >= t_end) {
+    if (BNB) for (int i = tid; i < 2 * C::CIN; i += 512) P.stats[(size_t)blockIdx.x * 2 * C::CIN + i] = 0.f;
+    return;
+  }
+  float* const ctab = reinterpret_cast<float*>(smem + C::CT_BASE);
+  if constexpr (BNB) {
+    for (int i = tid; i < 3 * C::CIN; i += 512)
+      ctab[i] = (i < C::CIN ? P.bn_scale : (i < 2 * C::CIN ? P.bn_shift : P.bn_mean))[i % C::CIN];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the tile loop's raw barrier does not wait for LDS writes)
+  }
+  float rs0[2][2][4], rs1[2][2][4];               // BNB: running sums [16-channel group][run][row] of this lane's channels
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rs0[a][b][j] = 0.f; rs1[a][b][j] = 0.f; }
 
   bf16x8 wreg[C::KGN];
   {
@@ -2263,6 +2288,9 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
       (void*)P.x, (short)0, (int)std::min<long long>(total_px * 4 * COUT * 2, 0x7FFFFFFFLL), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)P.y, (short)0, (int)std::min<long long>(total_px * C::CIN * 2, 0x7FFFFFFFLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bnrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(BNB ? P.bn_y : P.x), (short)0, (int)std::min<long long>(total_px * C::CIN * 2, 0x7FFFFFFFLL), 0x00020000);
+  (void)bnrs;
   typedef __attribute__((address_space(3))) void lds_void;
 
   int d_row[C::NDMA], d_z[C::NDMA], d_c[C::NDMA];
@@ -2274,18 +2302,18 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
     d_z[j] = pc / (COUT / 8);
     d_c[j] = (pc % (COUT / 8)) * 16;
   }
-  auto dma = [&](int tile, int buf) {
+  auto dma = [&](int tile, int buf, bool live = true) {
     const long long p0 = (long long)tile * C::TP;
 #pragma unroll
     for (int j = 0; j < C::NDMA; ++j) {
       const int idx = j * C::NWAVE + wave;
       const long long px = p0 + d_row[j];
-      const bool ok = d_row[j] >= 0 && px < total_px;
+      const bool ok = live && d_row[j] >= 0 && px < total_px;
       const int n = (int)(px / HW), rem = (int)(px - (long long)n * HW);
       const int y = rem / P.W, x = rem - y * P.W;
       const long long ipix = ((long long)n * 2 * P.H + 2 * y + (d_z[j] >> 1)) * (2 * P.W) + 2 * x + (d_z[j] & 1);
       const unsigned vo = ok ? (unsigned)(ipix * (COUT * 2) + d_c[j]) : OOB;
-      char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
+      char* dst = (live && idx < C::NINSTR) ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::NBUF * C::A_BYTES;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)dst, 16, vo, 0, 0, 0);
     }
   };
@@ -2298,7 +2326,23 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
     if (k >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (tile + 1 < t_end) dma(tile + 1, cur ^ 1);
+    // BNB: this tile's y values (same offsets as the stores) are requested FIRST, then the next tile's DMAs, so that the
+    // epilogue's wait for them leaves those DMAs in flight
+    u32x4 yv[BNB ? C::PXT : 1][2];
+    unsigned ovo[C::PXT][2];
+#pragma unroll
+    for (int pt = 0; pt < C::PXT; ++pt) {
+      const long long px = (long long)tile * C::TP + (wp * C::PXT + pt) * 32 + l31;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        ovo[pt][gp] = px < total_px ? (unsigned)((px * C::CIN + wr * 32 + 16 * gp + 8 * hh) * 2) : OOB;
+        // (inline asm: hipcc does not count LDS-DMA instructions, so its own wait for a builtin load issued in front of
+        //  the next tile's DMAs would be vmcnt(3) -- draining those DMAs every tile; the wait is hand-counted below)
+        if constexpr (BNB)
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(yv[pt][gp]) : "v"(ovo[pt][gp]), "s"(bnrs) : "memory");
+      }
+    }
+    if (BNB || tile + 1 < t_end) dma(tile + 1, cur ^ 1, tile + 1 < t_end);   // (BNB: always NDMA instructions -> one wait form)
 
     f32x16 acc[C::PXT];
 #pragma unroll
@@ -2308,7 +2352,7 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
     const char* pb = smem + cur * C::A_BYTES + (wp * C::PXT * 32 + l31) * C::RSTR + hh * 16;
     {
       // pixel fragments requested two K-groups ahead of their MFMAs, pinned (see conv3_ws_kernel)
-      constexpr int DEPTH = 2;
+      constexpr int DEPTH = BNB ? 1 : 2;            // (the fused form needs the registers for its sums and y values)
       bf16x8 ring[DEPTH + 1][C::PXT];
 #pragma unroll
       for (int i = 0; i < DEPTH && i < C::KGN; ++i)
@@ -2330,30 +2374,87 @@ __global__ __launch_bounds__(512, 1) void convt_dgrad_ws_kernel(const ConvTParam
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (BNB) {
+      // the y loads are older than the next tile's DMAs: leave exactly those in flight
+      static_assert(C::PXT == 2, "wait statement names 4 destinations");
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(yv[0][0]), "+v"(yv[0][1]), "+v"(yv[1][0]), "+v"(yv[1][1]) : "n"(C::NDMA));
+    }
 #pragma unroll
     for (int pt = 0; pt < C::PXT; ++pt) {
-      const long long px = (long long)tile * C::TP + (wp * C::PXT + pt) * 32 + l31;
-      const bool ok = px < total_px;
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {               // 16-byte stores (see convt_ws_kernel)
         bf16x4 xa, xb;
+        if constexpr (BNB) {
+          // y comes in with the store's 8-consecutive-channel layout: un-swap it to the accumulator's two 4-row runs
+          const u32x4 o = yv[pt][gp];
+          const auto o0 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+          const auto o1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+          const bf16x4 ya = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
+          const bf16x4 yb = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
+          const bool ok = ovo[pt][gp] != OOB;
+          const int cb = wr * 32 + 16 * gp + 4 * hh;
+          const f32x4 sca = *reinterpret_cast<const f32x4*>(ctab + cb), scb = *reinterpret_cast<const f32x4*>(ctab + cb + 8);
+          const f32x4 sha = *reinterpret_cast<const f32x4*>(ctab + C::CIN + cb);
+          const f32x4 shb = *reinterpret_cast<const f32x4*>(ctab + C::CIN + cb + 8);
+          const f32x4 mua = *reinterpret_cast<const f32x4*>(ctab + 2 * C::CIN + cb);
+          const f32x4 mub = *reinterpret_cast<const f32x4*>(ctab + 2 * C::CIN + cb + 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)acc[pt][8 * gp + j]; xb[j] = (bf16_t)acc[pt][8 * gp + 4 + j]; }
+          for (int j = 0; j < 4; ++j) {
+            const float fa = (float)ya[j], fb = (float)yb[j];
+            xa[j] = (bf16_t)((ok && fmaf(fa, sca[j], sha[j]) > 0.f) ? acc[pt][8 * gp + j] : 0.f);
+            xb[j] = (bf16_t)((ok && fmaf(fb, scb[j], shb[j]) > 0.f) ? acc[pt][8 * gp + 4 + j] : 0.f);
+            const float qa = (float)xa[j], qb = (float)xb[j];                // dz as stored
+            rs0[gp][0][j] += qa;
+            rs1[gp][0][j] = fmaf(qa, fa - mua[j], rs1[gp][0][j]);
+            rs0[gp][1][j] += qb;
+            rs1[gp][1][j] = fmaf(qb, fb - mub[j], rs1[gp][1][j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { xa[j] = (bf16_t)acc[pt][8 * gp + j]; xb[j] = (bf16_t)acc[pt][8 * gp + 4 + j]; }
+        }
         const u32x2 ua = __builtin_bit_cast(u32x2, xa), ub = __builtin_bit_cast(u32x2, xb);
         const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
-        const int r = wr * 32 + 16 * gp + 8 * hh;
-        const unsigned vo = ok ? (unsigned)((px * C::CIN + r) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, yrs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, yrs, ovo[pt][gp], 0, 0);
       }
+    }
+  }
+  if constexpr (BNB) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last tile's dummy DMAs)
+    // the block's partial: sums over the 32 pixel lanes of a half-wave (fixed butterfly order), then over the PW pixel
+    // waves through LDS, one store per (statistic, channel)
+    float* ex = ctab + 3 * C::CIN;                  // [PW][2][CIN]
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = rs0[gp][t][j], b = rs1[gp][t][j];
+#pragma unroll
+          for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+          if (l31 == 0) {
+            const int ch = wr * 32 + 16 * gp + 8 * t + 4 * hh + j;
+            ex[(wp * 2 + 0) * C::CIN + ch] = a;
+            ex[(wp * 2 + 1) * C::CIN + ch] = b;
+          }
+        }
+    __syncthreads();
+    for (int i = tid; i < 2 * C::CIN; i += 512) {
+      float t = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < C::PW; ++w2) t += ex[(w2 * 2 + i / C::CIN) * C::CIN + i % C::CIN];
+      P.stats[(size_t)blockIdx.x * 2 * C::CIN + i] = t;
     }
   }
 }
 
 template <int COUT>
-int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s) {
+int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s, int* n_parts = nullptr) {
   using C = CfgTD<COUT>;
-  auto kern = convt_dgrad_ws_kernel<COUT>;
+  const bool bnb = P.bn_y != nullptr;
+  auto kern = (bnb && COUT == 64) ? convt_dgrad_ws_kernel<COUT, (COUT == 64)> : convt_dgrad_ws_kernel<COUT, false>;
   unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long total_px = (long long)P.N * P.H * P.W;
   P.tiles = (int)cdiv64(total_px, C::TP);
@@ -2361,8 +2462,9 @@ int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s) {
   if (tpb < 2) tpb = 2;
   P.tiles_per_block = tpb;
   const long long blocks = cdiv64(P.tiles, tpb);
+  if (n_parts) *n_parts = (int)blocks;
   const double flops = 2.0 * total_px * 4.0 * COUT * C::CIN;
-  ProfScope prof(UNET_K_CONVT_DGRAD, flops, s, "convt_dgrad_ws_kernel");
+  ProfScope prof(UNET_K_CONVT_DGRAD, flops, s, bnb ? "convt_dgrad_ws_bnbwd_kernel" : "convt_dgrad_ws_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("convt_dgrad_ws_kernel");
 }
@@ -2599,7 +2701,7 @@ extern "C" int32_t unet_convt2x2_fwd(int32_t dtype, int32_t n, int32_t h, int32_
     const long long out_bytes = (long long)n * 4 * h * w * c_out * 2;
     if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_in == 128 || c_in == 256) && out_bytes < 0x7FFFFFFFLL &&
         unet_tuning().convt_impl != '0') {                     // (UNET_CONVT_IMPL=0: generic igemm path)
-      ConvTParams T{(const char*)x, (char*)y, (const char*)w_packed, bias, n, h, w, c_out, 0, 0};
+      ConvTParams T{(const char*)x, (char*)y, (const char*)w_packed, bias, n, h, w, c_out, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
       return c_in == 128 ? launch_convt_ws<128>(T, (hipStream_t)stream) : launch_convt_ws<256>(T, (hipStream_t)stream);
     }
   }
@@ -2632,7 +2734,7 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
     const long long in_bytes = (long long)n * 4 * h * w * c_out * 2;
     if (dtype == UNET_BF16 && c_in == 2 * c_out && (c_out == 64 || c_out == 128) && in_bytes < 0x7FFFFFFFLL &&
         unet_tuning().convt_impl != '0') {
-      ConvTParams T{(const char*)dy, (char*)dx, (const char*)w_packed, nullptr, n, h, w, c_out, 0, 0};
+      ConvTParams T{(const char*)dy, (char*)dx, (const char*)w_packed, nullptr, n, h, w, c_out, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
       return c_out == 64 ? launch_convt_dgrad_ws<64>(T, (hipStream_t)stream)
                          : launch_convt_dgrad_ws<128>(T, (hipStream_t)stream);
     }
@@ -2653,6 +2755,36 @@ extern "C" int32_t unet_convt2x2_dgrad(int32_t dtype, int32_t n, int32_t h, int3
   if (dtype == UNET_F32) return dispatch<float, 1>(P, UNET_K_CONVT_DGRAD, s);
   unet_set_error("unet_convt2x2_dgrad: dtype %d", dtype);
   return UNET_ERR_BAD_ARG;
+}
+
+// ---- data gradient of a transposed convolution fused with the ReLU mask and the BatchNorm-backward sums of the layer that
+// produced its input (the DoubleConv in front of an Up block, src/model.py:14-19 -> :51)
+extern "C" int32_t unet_convt2x2_dgrad_bnrelu_supported(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c_in,
+                                                        int32_t c_out) {
+  const long long in_bytes = (long long)n * 4 * h * w * c_out * 2;
+  // (c_out == 128 -- 128 weight registers per lane -- has no room for the running sums: 78 spills; not offered)
+  return (dtype == UNET_BF16 && c_in == 2 * c_out && c_out == 64 && in_bytes < 0x7FFFFFFFLL &&
+          unet_tuning().convt_impl != '0' && unet_tuning().dgrad_bn != '0') ? 1 : 0;
+}
+
+extern "C" size_t unet_convt2x2_dgrad_bnrelu_max_parts(void) { return 256; }
+
+extern "C" int32_t unet_convt2x2_dgrad_bnrelu(int32_t dtype, int32_t n, int32_t h, int32_t w, const void* dy, int32_t c_out,
+                                              const void* w_packed, const void* y_prev, const float* bn_scale,
+                                              const float* bn_shift, const float* bn_mean, void* dz, int32_t c_in,
+                                              float* partial, int32_t* n_parts, void* stream) {
+  UNET_REQUIRE(dy && w_packed && y_prev && bn_scale && bn_shift && bn_mean && dz && partial && n_parts, UNET_ERR_BAD_ARG,
+               "unet_convt2x2_dgrad_bnrelu: null pointer");
+  UNET_REQUIRE(n > 0 && h > 0 && w > 0, UNET_ERR_BAD_ARG, "unet_convt2x2_dgrad_bnrelu: bad dims");
+  UNET_REQUIRE(unet_convt2x2_dgrad_bnrelu_supported(dtype, n, h, w, c_in, c_out), UNET_ERR_UNSUPPORTED,
+               "unet_convt2x2_dgrad_bnrelu: %d <- %d channels at %dx%d (dtype %d) is not covered; use unet_convt2x2_dgrad + "
+               "unet_bn_relu_bwd", c_in, c_out, h, w, dtype);
+  ConvTParams T{(const char*)dy, (char*)dz, (const char*)w_packed, nullptr, n, h, w, c_out, 0, 0,
+                (const char*)y_prev, bn_scale, bn_shift, bn_mean, partial};
+  int parts = 0;
+  const int32_t rc = launch_convt_dgrad_ws<64>(T, (hipStream_t)stream, &parts);
+  *n_parts = parts;
+  return rc;
 }
 
 #ifdef PDMA_STAMPS

@@ -124,8 +124,10 @@ class DoubleConv(_HipBlock):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x, x_up=None, head=None, pool=False):
-        """``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
+    def forward(self, x, x_up=None, head=None, pool=False, out_link=None):
+        """``out_link`` (internal, optional): ops.BnLink to the ONE consumer of the result (the transposed convolution of
+        the next Up block), which then produces this block's last ReLU mask / BatchNorm-backward sums in its data gradient.
+        ``x_up`` (internal, optional): second channel block of the input, i.e. the up-sampled
         tensor of ``Up`` -- concatenated after ``x`` and centre-padded to its size on the fly.
         ``head`` (internal, optional): (OutConv, sigmoid) applied to the result -- in training mode the 1x1 head
         is fused with the last BatchNorm + ReLU (the activation is never written).
@@ -145,7 +147,10 @@ class DoubleConv(_HipBlock):
             a = _conv_bn_relu(seq[0], seq[1], x, x_up, out_link=link)
         fuse_pool = pool and ops.FUSE_BN_POOL and seq[4].training and a.shape[2] >= 2 and a.shape[3] >= 2 and \
             bool(ops.L.lib().unet_bn_relu_pool_supported(ops._DT[a.dtype], seq[3].out_channels))
-        out = _conv_bn_relu(seq[3], seq[4], a, None, in_link=link, head=head if fuse_head else None, pool=fuse_pool)
+        if fuse_head or fuse_pool or head is not None or pool:
+            out_link = None
+        out = _conv_bn_relu(seq[3], seq[4], a, None, in_link=link, out_link=out_link, head=head if fuse_head else None,
+                            pool=fuse_pool)
         if head is not None and not fuse_head:
             out = head[0](out, sigmoid=head[1])
         if pool and not fuse_pool:
@@ -184,15 +189,17 @@ class Up(_HipBlock):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels, out_channels, precision=precision)
 
-    def forward(self, x1, x2, head=None):
+    def forward(self, x1, x2, head=None, in_link=None, out_link=None):
+        """``in_link`` / ``out_link`` (internal, optional): ops.BnLink from the block that produced ``x1`` / to the one
+        consumer of the result (see DoubleConv.forward)."""
         dt = self.compute_dtype
         x1 = ops.to_operator_layout(x1, dt)
         x2 = ops.to_operator_layout(x2, dt)
         if self.bilinear:
             u = ops.Bilinear2x.apply(x1)
         else:
-            u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
-        return self.conv(x2, u, head=head)
+            u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias, in_link)
+        return self.conv(x2, u, head=head, out_link=out_link)
 
 
 class OutConv(_HipBlock):
@@ -258,6 +265,18 @@ def _encoder(m, x):
     return x1, x2, x3, x4, x5
 
 
+def _decoder_chain(up1, up2, up3, up4, feats, head):
+    """up1..up4 of one decoder (reference src/model.py:103-107 / :195-199 / :203-207).  The output of up1..up3 has exactly
+    one consumer, the next block's transposed convolution: a BnLink lets that kernel's data gradient produce the ReLU
+    mask and the BatchNorm-backward sums of the block's last conv-BN-ReLU (training only)."""
+    x1, x2, x3, x4, x5 = feats
+    links = [ops.BnLink() if (torch.is_grad_enabled() and up.training and not up.bilinear) else None for up in (up1, up2, up3)]
+    y = up1(x5, x4, out_link=links[0])
+    y = up2(y, x3, in_link=links[0], out_link=links[1])
+    y = up3(y, x2, in_link=links[1], out_link=links[2])
+    return up4(y, x1, head=head, in_link=links[2])
+
+
 class UNet(_HipBlock):
     def __init__(self, n_channels=3, n_classes=1, bilinear=False, precision=None):
         super().__init__()
@@ -283,11 +302,8 @@ class UNet(_HipBlock):
         ops._require_cuda(x)
         _pack_cache(self)
         with _BatchedCounters():
-            x1, x2, x3, x4, x5 = _encoder(self, x)
-            y = self.up1(x5, x4)
-            y = self.up2(y, x3)
-            y = self.up3(y, x2)
-            return self.up4(y, x1, head=(self.outc, bool(sigmoid)))
+            feats = _encoder(self, x)
+            return _decoder_chain(self.up1, self.up2, self.up3, self.up4, feats, (self.outc, bool(sigmoid)))
 
 
 class SegmentationUNet(_HipBlock):
@@ -330,10 +346,7 @@ class SegmentationUNet(_HipBlock):
         with _BatchedCounters():
             x1, x2, x3, x4, x5 = _encoder(self, x)
             x5 = self._bottleneck_dropout(x5)
-            y = self.up1(x5, x4)
-            y = self.up2(y, x3)
-            y = self.up3(y, x2)
-            return self.up4(y, x1, head=(self.outc, bool(sigmoid)))
+            return _decoder_chain(self.up1, self.up2, self.up3, self.up4, (x1, x2, x3, x4, x5), (self.outc, bool(sigmoid)))
 
 
 class AnomalyUNet(_HipBlock):
@@ -358,11 +371,8 @@ class AnomalyUNet(_HipBlock):
             setattr(self, f"outc_{branch}", OutConv(64, n_out, precision=precision))
 
     def _decode(self, feats, branch):
-        x1, x2, x3, x4, x5 = feats
-        y = getattr(self, f"up1_{branch}")(x5, x4)
-        y = getattr(self, f"up2_{branch}")(y, x3)
-        y = getattr(self, f"up3_{branch}")(y, x2)
-        return getattr(self, f"up4_{branch}")(y, x1, head=(getattr(self, f"outc_{branch}"), True))
+        ups = [getattr(self, f"up{i}_{branch}") for i in (1, 2, 3, 4)]
+        return _decoder_chain(*ups, feats, (getattr(self, f"outc_{branch}"), True))
 
     two_streams = os.environ.get("UNET_TWO_STREAMS", "1") != "0"   # run the two independent decoders on two HIP streams (their kernels fill each
                            # other's ramp-up / tail; autograd replays each branch's backward on its own stream)

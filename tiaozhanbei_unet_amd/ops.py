@@ -367,6 +367,7 @@ def _folded_pack(weight, gamma, beta, running_mean, running_var, co, ctot, dtype
 FUSE_BN_BWD = __import__("os").environ.get("UNET_FUSE_BN_BWD", "1") != "0"      # tuning hook (A/B runs)
 FUSE_BN_HEAD = __import__("os").environ.get("UNET_FUSE_BN_HEAD", "1") != "0"
 FUSE_BN_POOL = __import__("os").environ.get("UNET_FUSE_BN_POOL", "1") != "0"
+FUSE_BN_CONVT = __import__("os").environ.get("UNET_FUSE_BN_CONVT", "1") != "0"
 
 
 class BnLink:
@@ -803,7 +804,10 @@ class ConvT2x2(torch.autograd.Function):
     """nn.ConvTranspose2d(Cin, Cin//2, kernel_size=2, stride=2) (/root/reference/src/model.py:51)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, in_link=None):
+        """``in_link`` (BnLink, optional): ``x`` is the activation of a conv-BN-ReLU layer with no other consumer (the
+        DoubleConv of the previous Up block): the data-gradient kernel then applies that layer's ReLU mask and reduces
+        its BatchNorm-backward sums (unet_convt2x2_dgrad_bnrelu)."""
         _require_cuda(x, weight)
         n, ci, h, w = x.shape
         co = weight.shape[1]
@@ -814,6 +818,8 @@ class ConvT2x2(torch.autograd.Function):
                                           _stream()), "unet_convt2x2_fwd")
         ctx.save_for_backward(x, weight)
         ctx.keys = (weight.data_ptr(), bias.data_ptr())
+        ctx.in_link = in_link if (in_link is not None and in_link.y is not None and
+                                  in_link.y.data_ptr() != 0 and tuple(in_link.y.shape) == tuple(x.shape)) else None
         return y
 
     @staticmethod
@@ -828,14 +834,25 @@ class ConvT2x2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp = packed(weight, L.PACK_CONVT_DGRAD, ci, co, dtype)
             dx = _nhwc_empty(n, ci, h, w, dtype, dev)
-            L.check(lib.unet_convt2x2_dgrad(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(dx), ci, st),
-                    "unet_convt2x2_dgrad")
+            ilink = ctx.in_link if (FUSE_BN_BWD and FUSE_BN_CONVT) else None
+            if ilink is not None and ilink.y is not None and \
+                    lib.unet_convt2x2_dgrad_bnrelu_supported(_DT[dtype], n, h, w, ci, co):
+                part = torch.empty((lib.unet_convt2x2_dgrad_bnrelu_max_parts(), 2, ci), dtype=torch.float32, device=dev)
+                nparts = C.c_int32(0)
+                pc = ilink.coef
+                L.check(lib.unet_convt2x2_dgrad_bnrelu(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(ilink.y),
+                                                       _ptr(pc[2]), _ptr(pc[3]), _ptr(pc[0]), _ptr(dx), ci, _ptr(part),
+                                                       C.byref(nparts), st), "unet_convt2x2_dgrad_bnrelu")
+                ilink.partial, ilink.n_parts, ilink.dz_ptr = part, nparts.value, dx.data_ptr()
+            else:
+                L.check(lib.unet_convt2x2_dgrad(_DT[dtype], n, h, w, _ptr(dy), co, _ptr(wp), _ptr(dx), ci, st),
+                        "unet_convt2x2_dgrad")
         dw = grad_out(weight.shape, dev, ctx.keys[0])
         db = grad_out((co,), dev, ctx.keys[1])
         ws = _workspace(lib.unet_convt2x2_wgrad_workspace(n, h, w, ci, co), dev)
         L.check(lib.unet_convt2x2_wgrad(_DT[dtype], n, h, w, _ptr(x), ci, _ptr(dy), co, _ptr(dw), _ptr(db),
                                         _ptr(ws), ws.numel(), st), "unet_convt2x2_wgrad")
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class Bilinear2x(torch.autograd.Function):
