@@ -1726,7 +1726,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 
 #pragma unroll
   for (int d = 0; d < C::NBUF - 1; ++d)
-    if (ST || t_begin + d < t_end) dma_a(d, t_begin + d < t_end);
+    if (ST || STATS == 2 || t_begin + d < t_end) dma_a(d, t_begin + d < t_end);
   if constexpr (ST) {
     geometry();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");          // the first patch; the second one flies
@@ -1771,9 +1771,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
 #pragma unroll
       for (int pt = 0; pt < C::PXT; ++pt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) yv[pt][gp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ovo[pt][gp][0], 0, 0);
+        for (int gp = 0; gp < 2; ++gp)     // inline asm + the hand-counted wait below: hipcc does not count LDS-DMA
+                                           // instructions, its own wait for a builtin load here would drain the DMA ring
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(yv[pt][gp]) : "v"(ovo[pt][gp][0]), "s"(yrs) : "memory");
     }
-    if (ST || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
+    // (the statistics-2 form always issues its NDMA instructions -- dead ones to the dummy KiB -- so that one wait form
+    //  covers every tile)
+    if (ST || STATS == 2 || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
     // gradient fan-in (ACC): the old values are fetched NOW, behind the tile's 72 MFMAs (one load per output
     // run, from whichever view owns it and has its accumulate bit set; everything else reads as 0)
     u32x4 oldv[ACC ? C::PXT : 1][2];
@@ -1828,6 +1832,11 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (STATS == 2) {
+      static_assert(C::PXT == 2, "the wait statement names 4 destinations");
+      // the y loads are older than this tile's NDMA instructions: exactly those stay in flight
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(yv[0][0]), "+v"(yv[0][1]), "+v"(yv[1][0]), "+v"(yv[1][1]) : "n"(C::NDMA));
+    }
     if constexpr (ST) {
 #ifdef PDMA_STAMPS
       ws_dma_sum += ws_dma;
@@ -1964,7 +1973,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
     take_slots(t_end - 1 - t_begin);
     if (st_on) P.stats[((size_t)tr * 2 + st_q) * P.Cout + cg * C::ROWS + st_c] = stat_tot;
   }
-  if constexpr (ST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMAs before the wave ends
+  if constexpr (ST || STATS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMAs before the wave ends
 }
 
 int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
