@@ -28,12 +28,29 @@ namespace {
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int FIRST_CO = 64;
 
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-  return v;
+// sum over the 16 lanes of a DPP row, for N >= 3 independent values at once: v_add_f32 with a DPP source operand, one
+// instruction per value and step (quad xor 1, quad xor 2, half-row mirror, row mirror; fixed order -> deterministic).
+// Through __builtin_amdgcn_update_dpp hipcc emitted v_mov_b32 (old = 0) + v_mov_b32_dpp + half a v_pk_add_f32 per step
+// (its packed-add vectoriser defeats the DPP combine): 2.4x the instructions.  Step-major order + `asm volatile` (kept in
+// source order) puts N - 1 >= 2 instructions between the VALU write of a value and the DPP read of it -- the wait states
+// hipcc does not pad inside asm; one s_nop covers the producers of the inputs.  dst = dpp(src) + src: the same sums, bit
+// for bit.
+template <int N>
+__device__ __forceinline__ void row16_sum_n(float (&v)[N]) {
+  static_assert(N >= 3, "hazard distance");
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
 }
 
 // Position of a 16-pixel row segment; the kernels walk segments with a constant stride, so positions advance by
@@ -190,13 +207,18 @@ __global__ __launch_bounds__(256, 3) void first_fwd_kernel(const FirstParams P) 
   }
 
   if (P.part) {
+    {
+      float rv[32];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bs[ct][j] = row16_sum(bs[ct][j]);
-        bq[ct][j] = row16_sum(bq[ct][j]);
-      }
+        for (int j = 0; j < 4; ++j) { rv[ct * 4 + j] = bs[ct][j]; rv[16 + ct * 4 + j] = bq[ct][j]; }
+      row16_sum_n(rv);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bs[ct][j] = rv[ct * 4 + j]; bq[ct][j] = rv[16 + ct * 4 + j]; }
+    }
     if (l15 == 0) {
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)

@@ -875,12 +875,29 @@ int32_t launch3(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat_par
 // run of them, so the blocks of an XCD stream the same weight slabs and neighbouring halos through its L2.
 // sum over the 16 lanes of a DPP row, result in every lane: 4 VALU adds with DPP operands (quad xor 1, quad xor 2,
 // half-row mirror, row mirror) instead of 4 ds_bpermute + 4 adds; fixed order -> deterministic
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-  return v;
+// sum over the 16 lanes of a DPP row, for N >= 3 independent values at once: v_add_f32 with a DPP source operand, one
+// instruction per value and step (quad xor 1, quad xor 2, half-row mirror, row mirror; fixed order -> deterministic).
+// Through __builtin_amdgcn_update_dpp hipcc emitted v_mov_b32 (old = 0) + v_mov_b32_dpp + half a v_pk_add_f32 per step
+// (its packed-add vectoriser defeats the DPP combine): 2.4x the instructions.  Step-major order + `asm volatile` (kept in
+// source order) puts N - 1 >= 2 instructions between the VALU write of a value and the DPP read of it -- the wait states
+// hipcc does not pad inside asm; one s_nop covers the producers of the inputs.  dst = dpp(src) + src: the same sums, bit
+// for bit.
+template <int N>
+__device__ __forceinline__ void row16_sum_n(float (&v)[N]) {
+  static_assert(N >= 3, "hazard distance");
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
 }
 
 template <int BN>
@@ -1394,13 +1411,18 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       float tsum = 0.f;
       unsigned so = OOB;
       if (!DEFER || flush) {
+        {
+          float rv[2 * C::CT * 4];
 #pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct)
+          for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bs[ct][j] = row16_sum(bs[ct][j]);
-            bq[ct][j] = row16_sum(bq[ct][j]);
-          }
+            for (int j = 0; j < 4; ++j) { rv[ct * 4 + j] = bs[ct][j]; rv[C::CT * 4 + ct * 4 + j] = bq[ct][j]; }
+          row16_sum_n(rv);
+#pragma unroll
+          for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bs[ct][j] = rv[ct * 4 + j]; bq[ct][j] = rv[C::CT * 4 + ct * 4 + j]; }
+        }
         float* red = reinterpret_cast<float*>(smem + C::RED_BASE);     // [4 pixel-waves][2][BN]
         if (l15 == 0) {
 #pragma unroll
@@ -1926,11 +1948,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws_kernel(const IgemmParams P, i
         }
         if constexpr (STATS != 0) {
           float* rw = red + (k & 1) * 1024 + (wpx * 2 + ((lane >> 4) & 1)) * 64 + wco * 32 + 16 * gp + 4 * hh + 8 * t;
+          float rv[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float t0 = row16_sum(s0[j]), t1 = row16_sum(s1[j]);
-            if ((lane & 15) == 0) { rw[j] = t0; rw[512 + j] = t1; }
-          }
+          for (int j = 0; j < 4; ++j) { rv[j] = s0[j]; rv[4 + j] = s1[j]; }
+          row16_sum_n(rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((lane & 15) == 0) { rw[j] = rv[j]; rw[512 + j] = rv[4 + j]; }
         }
       }
 #pragma unroll
