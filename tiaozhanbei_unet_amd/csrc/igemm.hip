@@ -909,8 +909,11 @@ struct CfgP {
   static constexpr int NDA = (A_INSTR + 7) / 8;                      // 7 per wave
   static constexpr int W_BYTES = BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128) or 1 (BN 64) per wave
   static constexpr int NSLOT = 3;
-  static constexpr int W_BASE = 2 * A_BYTES;
-  static constexpr int RED_BASE = W_BASE + NSLOT * W_BYTES;          // BatchNorm partials of the epilogue
+  // the weight ring sits FIRST: slot * W_BYTES (<= 32 KiB) then folds into the 16-bit offset field of the fragment
+  // ds_reads (behind the patches, at 102 KiB, every read cost a v_add and the tap a spilled-SGPR v_readlane)
+  static constexpr int W_BASE = 0;
+  static constexpr int A_BASE = NSLOT * W_BYTES;
+  static constexpr int RED_BASE = A_BASE + 2 * A_BYTES;              // BatchNorm partials of the epilogue
   static constexpr int RED_BYTES = 4 * 2 * BN * 4;
   static constexpr int DUMMY = RED_BASE + RED_BYTES;
   static constexpr int LDS = DUMMY + 1024;
@@ -1010,7 +1013,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   auto dma_patch = [&](int chunk, int j, int buf, bool live) {
     const int idx = j * 8 + wave;
     live = live && idx < C::A_INSTR;
-    char* dst = live ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
+    char* dst = live ? smem + C::A_BASE + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
     const int ch = chunk * 64;
     if (ch < P.src[0].C) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[0], (lds_void*)dst, 16, live ? a_g[0][j] : OOB,
@@ -1161,7 +1164,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         d_live = has_next;
         if (has_next) setup_dma(wk + G);
       }
-      const int pbuf = pbuf_i * C::A_BYTES;
+      const int pbuf = C::A_BASE + pbuf_i * C::A_BYTES;
       if constexpr (PP) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
