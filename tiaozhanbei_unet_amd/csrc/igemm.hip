@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(512, 1) void conv3_pp128_bnbwd_kernel(const IgemmPa
 __global__ __launch_bounds__(512, 1) void conv3_pp64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, true>(P); }
 
 #ifdef PDMA_STAMPS
-void* g_pdma_debug = nullptr;
+void* g_pdma_debug = nullptr;      // (also read by wgrad.hip)
 #endif
 
 template <int BN>

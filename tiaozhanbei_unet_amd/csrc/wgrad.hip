@@ -22,7 +22,11 @@ namespace {
 
 struct WView { const char* p; int C, H, W, oy, ox; };
 
+#ifdef PDMA_STAMPS
+void* g_wgrad_debug = nullptr;   // diagnostic build only (unet_debug_set_buffer_wgrad)
+#endif
 struct WgradParams {
+  void* debug;     // diagnostic build: s_memtime sums per wave (tools/wgrad_stamps.py); nullptr otherwise
   WView rt;        // row tensor, geometry = frame
   WView ct[2];     // column tensor(s); channel tile below ct[0].C reads ct[0], else ct[1]
   int N, H, W;     // frame (pixel grid of the row tensor)
@@ -352,12 +356,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
   const int t_begin = sp * P.tilesPerSplit;
   const int t_end = min(t_begin + P.tilesPerSplit, ntiles);
 
+#ifdef PDMA_STAMPS
+  unsigned long long wg_st[4] = {0, 0, 0, 0}, wg_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long wg_t0 = wg_prev, wg_r0 = __builtin_amdgcn_s_memrealtime();
+#define WG_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wg_st[i] += t_ - wg_prev; wg_prev = t_; }
+#else
+#define WG_STAMP(i)
+#endif
   if (t_begin < t_end) dma(t_begin, 0);
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int buf = (tile - t_begin) & 1;
+    WG_STAMP(3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile `tile` has landed
+    WG_STAMP(0)
     __builtin_amdgcn_s_barrier();                               // ... everyone's has; buffer buf^1 is free
+    WG_STAMP(1)
     if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
+    WG_STAMP(2)
     const char* sR = smem + buf * C::BUF;
     const char* sC = sR + C::R_BYTES;
     if constexpr (REUSE) {
@@ -401,6 +416,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
     }
   }
 
+#ifdef PDMA_STAMPS
+  WG_STAMP(3)
+  if (P.debug && lane == 0 && blockIdx.x < 512) {
+    unsigned long long* o = (unsigned long long*)P.debug + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 4; ++i) o[i] = wg_st[i];
+    o[4] = (unsigned long long)(t_end - t_begin);
+    o[5] = ((__builtin_amdgcn_s_memtime() - wg_t0) << 20) / (__builtin_amdgcn_s_memrealtime() - wg_r0 + 1);
+  }
+#endif
   const int col = ctile * 64 + wc * 32 + l31;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
@@ -530,6 +554,9 @@ extern "C" int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32
   UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_conv3x3_wgrad: workspace %zu < %zu",
                workspace_bytes, pl.bytes);
   WgradParams P{};
+#ifdef PDMA_STAMPS
+  P.debug = g_wgrad_debug;
+#endif
   P.rt = WView{(const char*)dy, c_out, h, w, 0, 0};
   P.ct[0] = WView{(const char*)src[0].ptr, src[0].c, src[0].h, src[0].w, src[0].off_y, src[0].off_x};
   P.ct[1] = src[1].ptr ? WView{(const char*)src[1].ptr, src[1].c, src[1].h, src[1].w, src[1].off_y, src[1].off_x}
@@ -830,3 +857,7 @@ extern "C" int32_t unet_convt2x2_wgrad(int32_t dtype, int32_t n, int32_t h, int3
   // bias gradient: column sums of dy; the partial slabs above are consumed (stream order), reuse them
   return unet_internal_colsum(dtype, dy, (int64_t)n * 4 * h * w, c_out, db, (float*)workspace, workspace_bytes, s);
 }
+
+#ifdef PDMA_STAMPS
+extern "C" void unet_debug_set_buffer_wgrad(void* p) { g_wgrad_debug = p; }
+#endif
