@@ -44,6 +44,7 @@ void read_tuning() {
   g_tuning.dgrad_bn = first("UNET_DGRAD_BN");
   g_tuning.pdma_pp = first("UNET_PDMA_PP");
   g_tuning.ws_st = first("UNET_WS_ST");
+  g_tuning.ws_mfma = first("UNET_WS_MFMA");
 }
 std::mutex g_lds_mu;
 std::vector<std::pair<int, const void*>> g_lds_done;
