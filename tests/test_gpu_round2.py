@@ -466,3 +466,39 @@ def test_convt_dgrad_fused_with_batchnorm_backward(widths, n, h, monkeypatch):
         # a dy that may differ by one bf16 rounding where the sums differ in the last bit
         assert rel < (2e-4 if name == "conv.double_conv.4.weight" or name == "conv.double_conv.4.bias" else 2e-2), (name, rel)
     assert float((gx1 - gx0).norm() / gx0.norm()) < 2e-2
+
+
+def test_benchmark_config_is_bitwise_reproducible_and_linear_in_the_loss_scale():
+    """BASELINE.json configs[2] at FULL size (AnomalyUNet 3x256x256, bs=32, bf16, the persistent / ping-pong / 16x16x32
+    weight-stationary / GEMM kernels with > 256 work items each): size-independent properties.  (1) Two training steps
+    from the same seed are bitwise identical (every reduction is ordered: no float atomics anywhere on the path).
+    (2) The backward pass is linear in the loss: gradients of 2*loss are exactly 2x the gradients of loss (powers of two
+    commute with every bf16 / fp32 rounding), which holds only if every fused epilogue (ReLU masks, BatchNorm-backward
+    sums, premasked apply, gradient fan-in) is applied exactly once."""
+    import tiaozhanbei_unet_amd as P
+    from tiaozhanbei_unet_amd.train_utils import CombinedLoss
+
+    def run(scale):
+        torch.manual_seed(11)
+        model = P.AnomalyUNet(precision="bf16").to(DEV).train()
+        g = torch.Generator(device="cpu").manual_seed(3)
+        x = torch.randn(32, 3, 256, 256, generator=g).to(DEV)
+        mask = (torch.rand(32, 1, 256, 256, generator=g) < 0.02).float().to(DEV)
+        crit = CombinedLoss()
+        recon, amap = model(x)
+        loss = crit(recon, amap, x, mask)["total_loss"]
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        grads = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters()}
+        return float(loss), grads
+
+    l1, g1 = run(1.0)
+    l2, g2 = run(1.0)
+    assert l1 == l2
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"{k}: not bitwise reproducible at the benchmark size"
+    l3, g3 = run(2.0)
+    assert l3 == l1
+    for k in g1:
+        assert torch.equal(g3[k], 2.0 * g1[k]), f"{k}: backward is not linear in the loss scale"
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
