@@ -244,30 +244,31 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
 // output y, writes the activation a (the skip tensor) and its 2x2 max (the next level's input) -- the pool's own read
 // of a is gone.  A thread owns one window x 16 bytes of channels; (256 * PIECE) % C == 0, so its channel group -- and its
 // coefficients, in registers -- never change along the grid-stride loop.
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ a,
                                                                T* __restrict__ pooled, int N, int H, int W, int C) {
   constexpr int PIECE = ET<T>::PIECE;
+  typedef IDX idx_t;                               // int when every element index fits 31 bits (no 64-bit divisions)
   const int OH = H / 2, OW = W / 2, G = C / PIECE;
   const int WH = (H + 1) / 2, WW = (W + 1) / 2;   // windows incl. the ragged edge (its pixels get a, no pooled value)
-  const long long total = (long long)N * WH * WW * G;
+  const idx_t total = (idx_t)N * WH * WW * G;
   const int g = threadIdx.x % G;
   float sc[PIECE], sh[PIECE];
 #pragma unroll
   for (int j = 0; j < PIECE; ++j) { sc[j] = scale[g * PIECE + j]; sh[j] = shift[g * PIECE + j]; }
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long t = i / G;
+  for (idx_t i = (idx_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (idx_t)gridDim.x * 256) {
+    idx_t t = i / G;
     const int ox = (int)(t % WW);  t /= WW;
     const int oy = (int)(t % WH);
-    const long long n = t / WH;
-    const long long base = ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    const idx_t n = t / WH;
+    const idx_t base = ((n * H + 2 * oy) * W + 2 * ox) * (idx_t)C + g * PIECE;
     const bool ex = 2 * ox + 1 < W, ey = 2 * oy + 1 < H;
     float v[4][PIECE];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
-      const long long o = base + ((long long)(k >> 1) * W + (k & 1)) * C;
+      const idx_t o = base + ((idx_t)(k >> 1) * W + (k & 1)) * C;
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) v[k][j] = 0.f;
       if (ok) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     if (oy < OH && ox < OW) {
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) v[0][j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
-      Vec<T>::store(pooled + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), v[0]);
+      Vec<T>::store(pooled + (((n * OH + oy) * OW + ox) * (idx_t)C + g * PIECE), v[0]);
     }
   }
 }
@@ -290,17 +291,18 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 // this layer and the two BatchNorm-backward sums, in one pass: dz = da * [z > 0] (rounded to T exactly like the
 // unfused kernels round da), part[block][2][C] = (sum dz, sum dz * (y - mean)) -> unet_bn_bwd_premasked.  The window's
 // activations are recomputed from y (rounded like the stored ones), so a itself is not read.
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dpooled,
                                                                const T* da_old, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ mean, T* dz,
                                                                float* __restrict__ part, int N, int H, int W, int C) {
   constexpr int PIECE = ET<T>::PIECE;
+  typedef IDX idx_t;
   __shared__ float red[2][256][PIECE + 1];
   const int OH = H / 2, OW = W / 2, G = C / PIECE;
   const int WH = (H + 1) / 2, WW = (W + 1) / 2;
-  const long long total = (long long)N * WH * WW * G;
+  const idx_t total = (idx_t)N * WH * WW * G;
   const int g = threadIdx.x % G;
   float sc[PIECE], sh[PIECE], mu[PIECE], s0[PIECE], s1[PIECE];
 #pragma unroll
@@ -308,25 +310,25 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
     sc[j] = scale[g * PIECE + j]; sh[j] = shift[g * PIECE + j]; mu[j] = mean[g * PIECE + j];
     s0[j] = 0.f; s1[j] = 0.f;
   }
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long t = i / G;
+  for (idx_t i = (idx_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (idx_t)gridDim.x * 256) {
+    idx_t t = i / G;
     const int ox = (int)(t % WW);  t /= WW;
     const int oy = (int)(t % WH);
-    const long long n = t / WH;
-    const long long base = ((n * H + 2 * oy) * W + 2 * ox) * (long long)C + g * PIECE;
+    const idx_t n = t / WH;
+    const idx_t base = ((n * H + 2 * oy) * W + 2 * ox) * (idx_t)C + g * PIECE;
     const bool ex = 2 * ox + 1 < W, ey = 2 * oy + 1 < H, full = oy < OH && ox < OW;
     float yv[4][PIECE], av[4][PIECE], gr[PIECE];
     bool on[4][PIECE];
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) gr[j] = 0.f;
-    if (full) Vec<T>::load(dpooled + (((n * OH + oy) * OW + ox) * (long long)C + g * PIECE), gr);
+    if (full) Vec<T>::load(dpooled + (((n * OH + oy) * OW + ox) * (idx_t)C + g * PIECE), gr);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) { yv[k][j] = 0.f; av[k][j] = -1.f; on[k][j] = false; }
       if (ok) {
-        Vec<T>::load(y + base + ((long long)(k >> 1) * W + (k & 1)) * C, yv[k]);
+        Vec<T>::load(y + base + ((idx_t)(k >> 1) * W + (k & 1)) * C, yv[k]);
 #pragma unroll
         for (int j = 0; j < PIECE; ++j) {
           const float z = fmaf(yv[k][j], sc[j], sh[j]);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
     for (int k = 0; k < 4; ++k) {
       const bool ok = ((k & 1) == 0 || ex) && ((k >> 1) == 0 || ey);
       if (!ok) continue;
-      const long long o = base + ((long long)(k >> 1) * W + (k & 1)) * C;
+      const idx_t o = base + ((idx_t)(k >> 1) * W + (k & 1)) * C;
       float d[PIECE];
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) d[j] = 0.f;
@@ -600,12 +602,18 @@ extern "C" int32_t unet_bn_relu_pool_fwd(int32_t dtype, const void* y, int32_t n
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s, "bn_relu_pool_fwd_kernel");
   const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
-  if (dtype == UNET_BF16)
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
-                       (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
-  else
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale, shift,
-                       (float*)a, (float*)pooled, n, h, w, c);
+  const bool small = (long long)n * h * w * c < 0x7FFFFFFFLL;       // 32-bit element indices (no 64-bit divisions)
+  if (dtype == UNET_BF16) {
+    if (small)
+      hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<bf16_t, int>), dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y, scale,
+                         shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
+    else
+      hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<bf16_t, long long>), dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y,
+                         scale, shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
+  } else {
+    hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<float, long long>), dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale,
+                       shift, (float*)a, (float*)pooled, n, h, w, c);
+  }
   return unet_check_launch("bn_relu_pool_fwd_kernel");
 }
 
@@ -623,12 +631,18 @@ extern "C" int32_t unet_bn_relu_pool_bwd(int32_t dtype, const void* y, const voi
   ProfScope prof(UNET_K_POOL, 0.0, s, "bn_relu_pool_bwd_kernel");
   const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), POOL_BWD_MAX_BLOCKS);   // one partial per block
-  if (dtype == UNET_BF16)
-    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)dpooled,
-                       (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
-  else
-    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)y, (const float*)dpooled,
-                       (const float*)da_old, scale, shift, mean, (float*)dz, partial, n, h, w, c);
+  const bool small = (long long)n * h * w * c < 0x7FFFFFFFLL;
+  if (dtype == UNET_BF16) {
+    if (small)
+      hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<bf16_t, int>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y,
+                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
+    else
+      hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<bf16_t, long long>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y,
+                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
+  } else {
+    hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<float, long long>), dim3(blocks), dim3(256), 0, s, (const float*)y,
+                       (const float*)dpooled, (const float*)da_old, scale, shift, mean, (float*)dz, partial, n, h, w, c);
+  }
   *n_parts = blocks;
   return unet_check_launch("bn_relu_pool_bwd_kernel");
 }
