@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -160,3 +161,18 @@ def test_kolektorsdd_reader_contract(tmp_path):
     assert xb.shape == (3, 3, 96, 32) and mb.shape == (3, 96, 32) and len(pb) == 3
     tr2, _, _, _ = K.get_kolektorsdd_dataloaders(root, batch_size=2, image_size=(96, 32), num_workers=0, rank=1, world=2)
     assert len(tr2.sampler) == 7
+
+
+def test_inline_asm_dpp_reductions_keep_their_wait_states():
+    """The statistics epilogues reduce over DPP rows with inline-asm v_add_f32_dpp (csrc/igemm.hip, first.hip: row16_sum_n).
+    hipcc pads nothing inside an asm statement, so the helper's step-major order must leave two instructions between the
+    VALU write of a value and the DPP read of it: compile both sources to assembly (gfx950 cross-compile, no GPU) and scan
+    every DPP add (tools/check_dpp_hazards.py)."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "igemm.hip: " in r.stdout and " 0 hazards" in r.stdout
