@@ -603,7 +603,10 @@ def test_head_fused_with_batchnorm_relu(hip, dtype, co, sigmoid):
 DGRAD_BN_CASES = [  # n, c_dy, c_dx, h, w  -- two have > 256 work items per launch (persistent loop, block-mode sums);
     # 64 -> 64 runs on the weight-stationary streaming kernel (any frame size, several tiles per block, empty tile ranges)
     (2, 128, 128, 16, 32), (1, 256, 64, 32, 16), (3, 128, 256, 16, 16), (8, 128, 128, 128, 128), (5, 128, 64, 64, 96),
-    (2, 64, 64, 24, 40), (1, 64, 64, 9, 21), (4, 64, 64, 128, 144)]
+    (2, 64, 64, 24, 40), (1, 64, 64, 9, 21), (4, 64, 64, 128, 144),
+    # >= 512 gradient channels: the ping-pong instantiation (conv3_pp128_bnbwd_kernel) with several work items per block --
+    # 320 items on 256 blocks (ragged last round, per-tile partials) and 512 items (block-mode partials, two channel tiles)
+    (20, 512, 512, 32, 32), (16, 512, 256, 64, 64)]
 
 
 @pytest.mark.parametrize("case", DGRAD_BN_CASES, ids=str)
@@ -683,6 +686,11 @@ BIG_CONV_CASES = [  # > 256 work items of the persistent LDS-DMA kernels (the be
     (5, 128, 128, 64, 96),      # pdma128: 120 tiles -> per-tile statistics... and a partial last round
     (5, 128, 64, 128, 128),     # pdma64: 320 items, per-tile statistics
     (4, 256, 64, 128, 128),     # pdma64: 256 items per channel tile, block mode
+    # >= 512 input channels: the PING-PONG schedule (conv3_pp128_kernel; 46 % of the dominant kernel's launches in bench.py)
+    # walking several work items per block: cross-item DMA continuation, the after-epilogue vmcnt counts and the stagger
+    # barrier of the two wave groups only execute then
+    (20, 512, 512, 32, 32),     # 320 items on 256 blocks: ragged last round, per-tile statistics; dgrad is ping-pong too
+    (16, 512, 256, 64, 64),     # 512 items, two channel tiles, block-mode statistics (the shape class of up2.conv.0)
 ]
 
 
@@ -735,16 +743,23 @@ def test_conv3x3_persistent_kernels_many_work_items(hip, case):
     check(dw, wq.grad, dtype, "conv3x3 wgrad (many work items)", bf=5e-3)
 
 
-def test_conv3x3_persistent_two_source_many_work_items(hip):
+TWO_SOURCE_CASES = [  # n, c_skip, c_up, cout, h, w
+    (6, 64, 64, 128, 112, 128),     # lock-step kernel, 336 items
+    (20, 512, 512, 512, 32, 32),    # ping-pong kernel (1024 input channels = up1.conv.0), 320 items on 256 blocks
+]
+
+
+@pytest.mark.parametrize("case", TWO_SOURCE_CASES, ids=str)
+def test_conv3x3_persistent_two_source_many_work_items(hip, case):
     """Skip-concat form (two source views, src/model.py:65) on the persistent kernel with > 256 work items, and its
     two-destination data gradient."""
     L, ops = hip
     dtype = torch.bfloat16
     dt = ops._DT[dtype]
-    n, c0, c1, co, h, w = 6, 64, 64, 128, 112, 128
-    x2, x1 = rnd("b2_x2", (n, c0, h, w)), rnd("b2_x1", (n, c1, h, w))
-    wt = rnd("b2_w", (co, c0 + c1, 3, 3)) * 0.03
-    gy = rnd("b2_g", (n, co, h, w))
+    n, c0, c1, co, h, w = case
+    x2, x1 = rnd(f"b2_x2{case}", (n, c0, h, w)), rnd(f"b2_x1{case}", (n, c1, h, w))
+    wt = rnd(f"b2_w{case}", (co, c0 + c1, 3, 3)) * (1.0 / (3 * (c0 + c1) ** 0.5))
+    gy = rnd(f"b2_g{case}", (n, co, h, w))
     x2q, x1q, wq = q(x2, dtype).requires_grad_(True), q(x1, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True)
     ref = F.conv2d(torch.cat([x2q, x1q], 1), wq, padding=1)
     ref.backward(q(gy, dtype))
@@ -760,3 +775,10 @@ def test_conv3x3_persistent_two_source_many_work_items(hip):
                                  c0, 0, L.K_CONV_DGRAD, st()), "conv dgrad 2 dst")
     check(d2, x2q.grad, dtype, "two-destination dgrad, skip half")
     check(d1, x1q.grad, dtype, "two-destination dgrad, up half")
+    # weight gradient over the two column sources (the XCD-aware block order of wgrad_dma_kernel)
+    dw = torch.empty(co, c0 + c1, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, views(L, [(x2d, 0, 0), (x1d, 0, 0)]), p(gd), co, p(dw), c0 + c1, p(ws), need,
+                                       st()), "conv wgrad 2 src")
+    check(dw, wq.grad, dtype, "two-source wgrad", bf=5e-3)

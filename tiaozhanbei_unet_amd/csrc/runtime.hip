@@ -45,6 +45,8 @@ void read_tuning() {
   g_tuning.pdma_pp = first("UNET_PDMA_PP");
   g_tuning.ws_st = first("UNET_WS_ST");
   g_tuning.ws_mfma = first("UNET_WS_MFMA");
+  g_tuning.wgrad_xcd = first("UNET_WGRAD_XCD");
+  g_tuning.conv_xcd = first("UNET_CONV_XCD");
 }
 std::mutex g_lds_mu;
 std::vector<std::pair<int, const void*>> g_lds_done;

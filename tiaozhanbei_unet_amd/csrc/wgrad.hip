@@ -33,7 +33,38 @@ struct WgradParams {
   int Crow, Ccol;  // GEMM rows / cols (multiples of 64)
   float* partial;  // [split][TAPS][Crow][Ccol]
   int split, tilesPerSplit, tilesX, tilesY, nR, nC;
+  int xcd_chunk;   // > 0: XCD-aware block order (wgrad_block_coords), blocks per XCD; 0: plain order
 };
+
+// Block -> (split, row tile, column tile).  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own
+// L2.  XCD-aware order: XCD x owns the contiguous range [x*chunk, (x+1)*chunk) of the split-major list, i.e. whole
+// pixel ranges with ALL their (row, column) channel tiles -- the blocks that stream the same dY / X pixels run on one
+// L2 at the same time, so those bytes leave HBM/MALL once (plain order: the column tiles of one pixel range sit on
+// different XCDs and dY is fetched up to 8 times).  With fewer than 8 splits an XCD takes an 8x8 square of tiles.
+__device__ inline bool wgrad_block_coords(const WgradParams& P, int& sp, int& rtile, int& ctile) {
+  int b = blockIdx.x;
+  const int T = P.nR * P.nC;
+  if (P.xcd_chunk > 0) {
+    const int q = b >> 3;
+    b = (b & 7) * P.xcd_chunk + q;
+    if (q >= P.xcd_chunk || b >= P.split * T) return false;
+    sp = b / T;
+    int t = b - sp * T;
+    if (((P.nR | P.nC) & 7) == 0) {
+      const int tb = t >> 6, in = t & 63, cbn = P.nC >> 3;
+      rtile = (tb / cbn) * 8 + (in >> 3);
+      ctile = (tb % cbn) * 8 + (in & 7);
+    } else {
+      ctile = t % P.nC;
+      rtile = t / P.nC;
+    }
+    return true;
+  }
+  ctile = b % P.nC;  b /= P.nC;
+  rtile = b % P.nR;
+  sp = b / P.nR;
+  return true;
+}
 
 template <typename T, int TAPS>
 struct WCfg {
@@ -74,10 +105,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void wgrad_kernel(cons
   const int wr = wave & 1, wc = wave >> 1;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  int b = blockIdx.x;
-  const int ctile = b % P.nC;  b /= P.nC;
-  const int rtile = b % P.nR;
-  const int sp = b / P.nR;
+  int sp, rtile, ctile;
+  if (!wgrad_block_coords(P, sp, rtile, ctile)) return;
 
   // column source for this channel tile
   int cch = ctile * 64;
@@ -268,10 +297,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
   const int wr = wave & 1, wc = wave >> 1;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  int b = blockIdx.x;
-  const int ctile = b % P.nC;  b /= P.nC;
-  const int rtile = b % P.nR;
-  const int sp = b / P.nR;
+  int sp, rtile, ctile;
+  if (!wgrad_block_coords(P, sp, rtile, ctile)) return;
   int cch = ctile * 64;
   const WView CS = (cch < P.ct[0].C) ? P.ct[0] : P.ct[1];
   if (cch >= P.ct[0].C) cch -= P.ct[0].C;
@@ -494,7 +521,12 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
   unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   P.tilesX = pl.tilesX; P.tilesY = pl.tilesY; P.nR = pl.nR; P.nC = pl.nC;
   P.split = pl.split; P.tilesPerSplit = pl.tilesPerSplit;
-  const long long blocks = (long long)pl.split * pl.nR * pl.nC;
+  long long blocks = (long long)pl.split * pl.nR * pl.nC;
+  P.xcd_chunk = 0;
+  if (unet_tuning().wgrad_xcd != '0' && blocks >= 16) {         // UNET_WGRAD_XCD=0: plain block order
+    P.xcd_chunk = (int)cdiv64(blocks, 8);
+    blocks = 8LL * P.xcd_chunk;
+  }
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
   {
     ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)");
