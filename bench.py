@@ -18,7 +18,8 @@ Prints ONE JSON line (rank 0) with the driver's contract plus:
   roofline     -- the dominant KERNEL (most event time among the MFMA kernels), timed live with hipEvents on its own
                   stream (libunet_hip's per-launch brackets) against the dense MFMA peak of the dtype; `traffic` =
                   HBM bytes per launch of that kernel from the committed PMC passes of this same command
-                  (profiles/r02_pmc_traffic.json, tools/pmc_traffic.sh), beside its algorithmic bytes;
+                  (profiles/r03_pmc_traffic.json, tools/pmc_traffic.sh; quoted only when that summary was taken from
+                  THIS build -- same sha256 of csrc/ -- else null), beside the algorithmic bytes of the same launches;
   cpu_baseline -- the CPU oracle (a port of the reference's train step) timed on this box's host cores
                   on a bounded sample (N=1 only).
 """
@@ -35,7 +36,18 @@ sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_IMG_256 = {"anomaly_unet": 158.637, "unet": 96.335}      # SURVEY 8(d), forward, 256x256
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources: ties a committed PMC summary to the build it was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tiaozhanbei_unet_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -101,17 +113,6 @@ def cpu_baseline(size, batch, model):
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{steps} timed steps ({dt:.1f} s, after 1 warm-up) of the oracle train step, {name} "
                       f"{size}x{size} bs={batch} fp32, torch {torch.__version__} CPU"}
-
-
-def layer_bytes(model, n, s, es):
-    """Algorithmic bytes (input + weights + output, each once) of the 3x3 convolutions of one forward, per layer:
-    [(cin, cout, hw, bytes)].  Used for the algorithmic-bytes figure beside roofline.traffic."""
-    enc = [(3, 64, s), (64, 64, s), (64, 128, s // 2), (128, 128, s // 2), (128, 256, s // 4), (256, 256, s // 4),
-           (256, 512, s // 8), (512, 512, s // 8), (512, 1024, s // 16), (1024, 1024, s // 16)]
-    dec = [(1024, 512, s // 8), (512, 512, s // 8), (512, 256, s // 4), (256, 256, s // 4), (256, 128, s // 2),
-           (128, 128, s // 2), (128, 64, s), (64, 64, s)]
-    layers = enc + dec * (2 if model == "anomaly_unet" else 1)
-    return [(ci, co, hw, n * hw * hw * (max(ci, 64) + co) * es + 9 * ci * co * es) for ci, co, hw in layers]
 
 
 def main():
@@ -199,6 +200,8 @@ def main():
 
     # ---- roofline of the dominant kernel: hipEvent brackets inside libunet_hip, 2 extra steps
     roof = None
+    default_cfg = (args.model == "anomaly_unet" and args.precision == "bf16" and args.batch == 32 and args.size == 256
+                   and not args.ssim and args.mask == "bernoulli")
     if not args.no_roofline:
         # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
         # The two decoder branches normally run on two HIP streams; for these two steps they run on ONE stream so
@@ -220,27 +223,35 @@ def main():
                 d = mfma[name]
                 achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 peak = PEAK[args.precision]
-                es = 2 if args.precision == "bf16" else 4
-                traffic, traffic_note = None, "no PMC summary for this kernel in profiles/r02_pmc_traffic.json"
+                traffic, traffic_note, traffic_src = None, "no PMC summary for this kernel in " + os.path.basename(PMC_FILE), None
                 try:
-                    pmc = json.load(open(PMC_FILE))["kernels"]
+                    pmc_all = json.load(open(PMC_FILE))
+                    pmc = pmc_all["kernels"]
+                    traffic_src = pmc_all.get("csrc_sha16")
                     key = name.split(" ")[0]
-                    # a bracket name covers the lock-step (pdma) and ping-pong (pp) instantiations of one kernel body
+                    # a bracket name covers the lock-step (pdma) and ping-pong (pp) instantiations of one kernel body;
+                    # "(+ reduce)" brackets also cover the split-K reduction kernels that follow the main kernel
                     fam = [k for k in pmc if k.split("<")[0] in (key, key.replace("_pdma", "_pp"))]
-                    if fam:
-                        nl = sum(pmc[k]["launches"] for k in fam)
+                    main = list(fam)
+                    if "(+ reduce)" in name:
+                        fam += [k for k in pmc if k.split("<")[0].startswith(key.split("_")[0] + "_reduce")]
+                    if main and default_cfg and traffic_src == csrc_sha16():
+                        nl = sum(pmc[k]["launches"] for k in main)
                         traffic = int(sum(pmc[k]["traffic_bytes_per_launch"] * pmc[k]["launches"] for k in fam) / nl)
-                        traffic_note = ("bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from the rocprofv3 --pmc passes of "
-                                        "this command (profiles/r02_pmc_traffic.json; default config only; launch-weighted "
-                                        "over " + ", ".join(sorted(fam)) + ")")
+                        traffic_note = ("bytes per launch, 2*FETCH_SIZE + WRITE_SIZE (KiB units, gfx950 x2 on FETCH) from the "
+                                        "rocprofv3 --pmc passes of this command on this build (" + os.path.basename(PMC_FILE) +
+                                        ", tools/pmc_traffic.sh; launch-weighted over " + ", ".join(sorted(fam)) + ")")
+                    elif main:
+                        traffic_note = ("PMC summary " + os.path.basename(PMC_FILE) + " was taken from another build or "
+                                        "configuration (csrc sha " + str(traffic_src) + " vs " + csrc_sha16() + "): not quoted")
                 except (OSError, ValueError, KeyError):
                     pass
-                # algorithmic bytes of the layers that kernel serves (>= 128 input channels, forward + data gradient)
-                lb = [b for (ci, co, hw, b) in layer_bytes(args.model, n, s, es) if ci >= 128]
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                         "traffic_note": traffic_note,
-                        "algorithmic_bytes_per_launch": int(sum(lb) / max(len(lb), 1)) if "pdma" in name else None,
+                        "traffic_csrc_sha16": traffic_src,
+                        # input + weights + output of exactly the launches this bracket covered (stated by the launcher)
+                        "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]) if d.get("bytes") else None,
                         "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
                         "measured": "hipEvent brackets on the launch stream, 2 single-stream steps after the timed region",
                         "per_kernel_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},

@@ -73,6 +73,9 @@ int32_t unet_prof_collect(double* ms, int64_t* launches, double* flops);
 /* Per-KERNEL breakdown of the brackets consumed by the last unet_prof_collect(): entry `index` (0, 1, ... until
  * UNET_ERR_BAD_ARG) -> kernel name (static string), summed event time, launches, algorithmic FLOPs. */
 int32_t unet_prof_kernel_stats(int32_t index, const char** name, double* ms, int64_t* launches, double* flops);
+/* Algorithmic bytes (inputs + weights + outputs, each once) summed over the launches of entry `index` of the same
+ * breakdown; 0 for kernels whose launcher does not state them (the figure roofline.traffic is held against). */
+int32_t unet_prof_kernel_bytes(int32_t index, double* bytes);
 
 /* ---- layout ------------------------------------------------------------------------- */
 /* NCHW fp32 -> NHWC compute dtype with the channel dim zero-padded to c_pad

@@ -176,3 +176,29 @@ def test_inline_asm_dpp_reductions_keep_their_wait_states():
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "igemm.hip: " in r.stdout and " 0 hazards" in r.stdout
+
+
+def test_fused_adam_takes_a_torch_adam_state_dict():
+    """torch's load_state_dict replaces param_groups with the saved ones -- a torch.optim.Adam / AdamW checkpoint
+    (what the reference writes, src/utils.py:39-44) has no `decoupled` key and may carry device `step` scalars.  The host
+    side of the fix is checkable without a GPU: the key is derived from torch's `decoupled_weight_decay`, steps become
+    host fp32 scalars."""
+    import torch
+    from tiaozhanbei_unet_amd.optim import FusedAdam
+    for Opt, dec in ((torch.optim.Adam, False), (torch.optim.AdamW, True)):
+        ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+        ref = Opt(ps, lr=1e-3, weight_decay=1e-4)
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        ref.step()
+        ref.step()
+        fused = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3, decoupled=not dec)
+        fused.load_state_dict(ref.state_dict())
+        assert fused.param_groups[0]["decoupled"] is dec
+        assert fused.param_groups[0]["weight_decay"] == 1e-4
+        for st in fused.state.values():
+            assert st["step"].dtype == torch.float32 and st["step"].device.type == "cpu" and float(st["step"]) == 2.0
+        # and its own state_dict round-trips (the key survives)
+        again = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+        again.load_state_dict(fused.state_dict())
+        assert again.param_groups[0]["decoupled"] is dec

@@ -39,6 +39,7 @@ SIGNATURES = {
     "unet_prof_enable": (_i, [_i]),
     "unet_prof_collect": (_i, [_p, _p, _p]),
     "unet_prof_kernel_stats": (_i, [_i, _p, _p, _p, _p]),
+    "unet_prof_kernel_bytes": (_i, [_i, _p]),
     "unet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_pack_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

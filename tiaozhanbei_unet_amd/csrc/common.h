@@ -38,13 +38,15 @@ void unet_set_max_lds(const void* kernel, int bytes);
 
 // ---- per-class event timing (prof.cpp) ---------------------------------------------------
 void unet_prof_begin(int kclass, hipStream_t s);
-void unet_prof_end(int kclass, double flops, hipStream_t s, const char* kernel);
+void unet_prof_end(int kclass, double flops, hipStream_t s, const char* kernel, double bytes);
 struct ProfScope {
   int k; double f; hipStream_t s; const char* name;      // name: static string naming the (dominant) kernel of the bracket
-  ProfScope(int kclass, double flops, hipStream_t st, const char* kernel = nullptr) : k(kclass), f(flops), s(st), name(kernel) {
+  double bytes;                                          // algorithmic bytes of the launch: inputs + weights + outputs, each once
+  ProfScope(int kclass, double flops, hipStream_t st, const char* kernel = nullptr, double alg_bytes = 0.0)
+      : k(kclass), f(flops), s(st), name(kernel), bytes(alg_bytes) {
     unet_prof_begin(k, s);
   }
-  ~ProfScope() { unet_prof_end(k, f, s, name); }
+  ~ProfScope() { unet_prof_end(k, f, s, name, bytes); }
 };
 
 // the deep transposed convolutions as one LDS-DMA GEMM (convt_gemm.hip); mode 0 forward, 1 data gradient

@@ -1528,8 +1528,12 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   if (!bnbwd) P.bn_mean = (const float*)g_pdma_debug;
 #endif
   // (one bracket name per body: the lock-step and ping-pong instantiations of conv3_pdma_body<BN> are one kernel family)
+  // algorithmic bytes: input + packed weights + output, each once (+ y of the fused BatchNorm-backward form, + the old
+  // values of an accumulating epilogue), bf16
+  const double px = (double)P.N * P.H * P.W;
+  const double alg_bytes = 2.0 * (px * (P.Ctot + P.Cout * (1.0 + (bnbwd ? 1 : 0) + (P.accumulate ? 1 : 0))) + 9.0 * P.Ctot * P.Cout);
   ProfScope prof(kclass, flops, s, bnbwd ? (BN == 128 ? "conv3_pdma128_bnbwd_kernel" : "conv3_pdma64_bnbwd_kernel")
-                                          : (BN == 128 ? "conv3_pdma128_kernel" : "conv3_pdma64_kernel"));
+                                          : (BN == 128 ? "conv3_pdma128_kernel" : "conv3_pdma64_kernel"), alg_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
   return unet_check_launch("conv3_pdma_kernel");
 }
@@ -2412,8 +2416,10 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
     if (mode == 0) P.stats = nullptr;
     if (stat_parts) *stat_parts = mode ? (int)ranges : 0;
     unet_set_max_lds(reinterpret_cast<const void*>(k16), CfgWS16::LDS);
+    const double px16 = (double)P.N * P.H * P.W;
     ProfScope prof(kclass, 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9, s,
-                   mode == 2 ? "conv3_ws_bnbwd_kernel" : "conv3_ws_kernel");
+                   mode == 2 ? "conv3_ws_bnbwd_kernel" : "conv3_ws_kernel",
+                   2.0 * (px16 * (P.Ctot + P.Cout * (1.0 + (mode == 2 ? 1 : 0) + (P.accumulate ? 1 : 0))) + 9.0 * P.Ctot * P.Cout));
     hipLaunchKernelGGL(k16, dim3((unsigned)(ranges * nCg16)), dim3(512), CfgWS16::LDS, s, P, tpb16);
     return unet_check_launch("conv3_ws16_kernel");
   }

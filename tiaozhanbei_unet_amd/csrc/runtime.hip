@@ -75,8 +75,8 @@ void unet_set_max_lds(const void* kernel, int bytes) {
 
 // ------------------------------------------------------------------------------ profiling
 namespace {
-struct Rec { int k; double flops; hipEvent_t a, b; const char* name; };
-struct KStat { const char* name; double ms; long long launches; double flops; };
+struct Rec { int k; double flops; hipEvent_t a, b; const char* name; double bytes; };
+struct KStat { const char* name; double ms; long long launches; double flops; double bytes; };
 std::vector<KStat> g_kstats;                      // per-kernel aggregation of the last unet_prof_collect()
 std::mutex g_mu;
 bool g_on = false;
@@ -99,13 +99,13 @@ void unet_prof_begin(int, hipStream_t s) {
   if (t_start) (void)hipEventRecord(t_start, s);
 }
 
-void unet_prof_end(int k, double flops, hipStream_t s, const char* kernel) {
+void unet_prof_end(int k, double flops, hipStream_t s, const char* kernel, double bytes) {
   if (!g_on || !t_start) return;
   std::lock_guard<std::mutex> l(g_mu);
   hipEvent_t b = get_event();
   if (!b) return;
   (void)hipEventRecord(b, s);
-  g_recs.push_back({k, flops, t_start, b, kernel});
+  g_recs.push_back({k, flops, t_start, b, kernel, bytes});
   t_start = nullptr;
 }
 
@@ -128,8 +128,8 @@ extern "C" int32_t unet_prof_collect(double* ms, int64_t* launches, double* flop
       if (r.name) {
         KStat* ks = nullptr;
         for (auto& e : g_kstats) if (e.name == r.name || strcmp(e.name, r.name) == 0) { ks = &e; break; }
-        if (!ks) { g_kstats.push_back({r.name, 0.0, 0, 0.0}); ks = &g_kstats.back(); }
-        ks->ms += t; ks->launches += 1; ks->flops += r.flops;
+        if (!ks) { g_kstats.push_back({r.name, 0.0, 0, 0.0, 0.0}); ks = &g_kstats.back(); }
+        ks->ms += t; ks->launches += 1; ks->flops += r.flops; ks->bytes += r.bytes;
       }
     }
     g_pool.push_back(r.a);
@@ -145,5 +145,14 @@ extern "C" int32_t unet_prof_kernel_stats(int32_t index, const char** name, doub
   UNET_REQUIRE(index >= 0 && index < (int)g_kstats.size(), UNET_ERR_BAD_ARG, "unet_prof_kernel_stats: index %d of %zu", index,
                g_kstats.size());
   *name = g_kstats[index].name; *ms = g_kstats[index].ms; *launches = g_kstats[index].launches; *flops = g_kstats[index].flops;
+  return UNET_OK;
+}
+
+extern "C" int32_t unet_prof_kernel_bytes(int32_t index, double* bytes) {
+  UNET_REQUIRE(bytes, UNET_ERR_BAD_ARG, "unet_prof_kernel_bytes: null output");
+  std::lock_guard<std::mutex> l(g_mu);
+  UNET_REQUIRE(index >= 0 && index < (int)g_kstats.size(), UNET_ERR_BAD_ARG, "unet_prof_kernel_bytes: index %d of %zu", index,
+               g_kstats.size());
+  *bytes = g_kstats[index].bytes;
   return UNET_OK;
 }

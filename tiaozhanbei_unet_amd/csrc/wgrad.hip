@@ -529,7 +529,11 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
   }
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
   {
-    ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)");
+    // algorithmic bytes: both activation tensors once + the fp32 gradient once (split-K slabs are overhead, not counted)
+    const double alg_bytes = (double)P.N * P.H * P.W * ((double)P.Crow + P.Ccol * (TAPS == 9 ? 1.0 : 4.0)) * sizeof(T) +
+                             4.0 * TAPS * rows_out * cols_out;
+    ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)",
+                   alg_bytes);
     const char impl = unet_tuning().wgrad_impl;                 // UNET_WGRAD_IMPL: '0' = register-staged kernel
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
       if (impl != '0') {

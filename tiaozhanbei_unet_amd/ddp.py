@@ -13,9 +13,10 @@ slice: the two decoder branches of AnomalyUNet run on two), so the big decoder/b
 encoder backward is still running.  ``finish()`` waits for the outstanding collectives before the optimiser step.
 
 Bucket ORDER: the first step uses reverse registration order (~ the order backward produces gradients); the order in
-which the hooks actually fired in that step is recorded, and before the next forward the buckets are rebuilt in it -- a
-bucket then fills with gradients that complete together (registration order interleaves the two decoders, which finish
-on different streams).  BatchNorm statistics stay per-GPU (standard DDP semantics).
+which the hooks actually fired in that step ON RANK 0 is recorded and broadcast, and before the next forward every rank
+rebuilds its buckets in it -- a bucket then fills with gradients that complete together (registration order interleaves
+the two decoders, which finish on different streams), and all ranks provably share one layout.  BatchNorm statistics
+stay per-GPU (standard DDP semantics).
 """
 from __future__ import annotations
 
@@ -148,9 +149,21 @@ class GradientExchange:
                 self.buckets[bi].div_(self.world)
         self._handles.clear()
         self._pending = list(self._count)
-        if not self._reordered and self._reorder is None and len(self._fired) == len(self.params):
-            if [id(p) for p in self._fired] != [id(p) for ps in self._bucket_plan() for p in ps]:
-                self._reorder = list(self._fired)
+        if not self._reordered and self._reorder is None:
+            # Every rank must lay its buckets out identically (they all-reduce flat buffers): rank 0's completion order
+            # is the one everybody adopts -- the engine's hook order is not guaranteed to agree across ranks (two
+            # decoder streams).  One small broadcast, once per run; a rank-0 step that missed a parameter keeps the
+            # initial layout everywhere.
+            index = {id(p): i for i, p in enumerate(self.params)}
+            mine = [index[id(p)] for p in self._fired] if len(self._fired) == len(self.params) else []
+            msg = torch.tensor([1 if mine else 0] + (mine or [0] * len(self.params)), dtype=torch.int64,
+                               device=self.buckets[0].device)
+            dist.broadcast(msg, src=0, group=self.group)
+            vals = msg.tolist()
+            order = [self.params[i] for i in vals[1:]] if vals[0] else None
+            if order is not None and sorted(vals[1:]) == list(range(len(self.params))) and \
+                    [id(p) for p in order] != [id(p) for ps in self._bucket_plan() for p in ps]:
+                self._reorder = order
             else:
                 self._reordered = True
         self._fired = []

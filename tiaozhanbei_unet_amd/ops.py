@@ -566,12 +566,18 @@ class ConvBnRelu(torch.autograd.Function):
                                               _ptr(dy), _ptr(ws), ws.numel(), st), "unet_bn_bwd_premasked")
         elif ctx.pool and dpooled is not None:
             # pooled gradient routed + added to the skip's gradient buffer + ReLU mask + BatchNorm-backward sums: one pass
+            own = False            # `da` is the GradSink buffer of this skip: nobody else holds it, safe to overwrite
             if da is not None:
+                if ctx.out_sink is not None and ctx.out_sink.buf is not None and \
+                        da.data_ptr() == ctx.out_sink.buf.data_ptr():
+                    own = True
                 if ctx.out_sink is not None:
                     ctx.out_sink.collect(da, dev)
                 da = _as_nhwc(da, dtype)
             dpooled = _as_nhwc(dpooled, dtype)
-            dy = da if da is not None else _nhwc_empty(n, co, h, w, dtype, dev)      # in place over the skip's buffer
+            # in place over the skip's own gradient buffer; a gradient autograd delivered from elsewhere may be shared
+            # with another node (e.g. add-backward hands one tensor to both inputs) and is left untouched
+            dy = da if own else _nhwc_empty(n, co, h, w, dtype, dev)
             part = torch.empty((lib.unet_bn_relu_pool_max_parts(), 2, co), dtype=torch.float32, device=dev)
             nparts = C.c_int32(0)
             L.check(lib.unet_bn_relu_pool_bwd(dt, _ptr(y), _ptr(dpooled), _ptr(da), n, h, w, co, _ptr(coef[2]),
@@ -1018,7 +1024,9 @@ def prof_kernels():
         name, ms, n, fl = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double()
         if lib.unet_prof_kernel_stats(i, C.byref(name), C.byref(ms), C.byref(n), C.byref(fl)) != 0:
             break
-        out[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
+        by = C.c_double()
+        lib.unet_prof_kernel_bytes(i, C.byref(by))
+        out[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         i += 1
     return out
 

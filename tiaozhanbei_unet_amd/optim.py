@@ -25,6 +25,29 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self._tables = {}          # group index -> cached descriptor / chunk tables
 
+    def _normalise_loaded(self):
+        """After ``load_state_dict`` / unpickling: a checkpoint written by ``torch.optim.Adam`` / ``AdamW`` (the reference's
+        optimisers, src/train_utils.py:266-268) carries no ``decoupled`` key -- torch names it ``decoupled_weight_decay`` --
+        and, loaded with ``map_location=device`` (src/utils.py:52), its per-parameter ``step`` scalars sit on the GPU:
+        the update rule is taken from torch's key and every ``step`` goes back to a host fp32 scalar (reading a device
+        scalar would be one host sync per parameter per step)."""
+        for group in self.param_groups:
+            group.setdefault("decoupled", bool(group.get("decoupled_weight_decay", False)))
+        for st in self.state.values():
+            if "step" in st:
+                v = st["step"]
+                st["step"] = torch.tensor(float(v), dtype=torch.float32)       # (one sync per tensor, once per load)
+        self._tables = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._normalise_loaded()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("grad_scale", 1.0)
+        self._normalise_loaded()
+
     def _init_state(self, p):
         st = self.state[p]
         if not st:

@@ -49,10 +49,13 @@ class CombinedLoss(nn.Module):
         return ops.MseFocal.apply(zero, pred, zero, target, self.focal_alpha, self.focal_gamma)[1]
 
     def forward(self, reconstruction, anomaly_map, original_image, true_mask):
-        recon_loss, seg_loss = ops.MseFocal.apply(reconstruction, anomaly_map, original_image, true_mask,
-                                                  self.focal_alpha, self.focal_gamma)
         if self.recon_criterion is not None:
+            # (the reference's dead --use_ssim switch, src/train.py:191-194, made live: SSIM head + focal)
             recon_loss = self.recon_criterion(reconstruction, original_image)
+            seg_loss = self.focal_loss(anomaly_map, true_mask)
+        else:
+            recon_loss, seg_loss = ops.MseFocal.apply(reconstruction, anomaly_map, original_image, true_mask,
+                                                      self.focal_alpha, self.focal_gamma)
         total = self.recon_weight * recon_loss + self.seg_weight * seg_loss
         return {"total_loss": total, "recon_loss": recon_loss, "seg_loss": seg_loss}
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes of bench.py into per-kernel HBM traffic (profiles/r02_pmc_traffic.json).
+"""Summarise rocprofv3 --pmc passes of bench.py into per-kernel HBM traffic (profiles/rNN_pmc_traffic.json).
 
     tools/pmc_summarize.py <FETCH_SIZE dir> <WRITE_SIZE dir> <MFMA dir|-> <out.json>
 
@@ -56,7 +56,10 @@ def main():
             rec["mfma_busy_frac"] = round(busy / (act / 8.0 * 1024.0), 4)      # 1024 SIMDs; GRBM summed over 8 XCDs
         kernels[k] = rec
     top = sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes of `python3 bench.py "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha16
+    json.dump({"csrc_sha16": csrc_sha16(), "commit": os.environ.get("UNET_COMMIT", "unknown"),
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes of `python3 bench.py "
                          "--steps 3 --warmup 2 --blocks 1 --no-cpu-baseline --no-roofline` (tools/pmc_traffic.sh), "
                          "UNET_TWO_STREAMS=0; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per launch",
                "kernels": dict(top)}, open(dst, "w"), indent=1)
