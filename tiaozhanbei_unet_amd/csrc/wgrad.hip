@@ -464,6 +464,258 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// wgrad16_kernel<NRH, NCH, PAIRED> (round 3): the bf16 conv3x3 weight gradient on v_mfma_f32_16x16x32_bf16.
+//
+// Why: the 32x32x16 kernel above ran at 1.23-1.58 GHz in-kernel (profiles/r02_wgrad_stamps.txt) -- the chip holds a
+// higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7) -- and ~36 % of a tile went to its ten
+// one-KiB LDS-DMA issues per wave.  Here:
+//  * one 512-thread block per CU owns 128 x 64 (NRH=2, NCH=1) or 64 x 128 (1, 2) gradient channels x 9 taps: the X patch
+//    (or the dY tile) is staged once for twice the MFMAs -- 62 instead of 78 KiB of LDS-DMA per 18.9 MFLOP;
+//  * K = 32 pixels per MFMA = one 32-pixel tile ROW (tile 4 x 32; PAIRED, W <= 16: 16 pixels of image n + 16 of image
+//    n+1), so the X fragment of (patch row p, column shift s) still serves the three (tile row, tap row) pairs with
+//    ty + r = p; the loop walks PATCH rows: per row 6 X fragments + 2 dY fragments (a 4-slot ring of dY rows), 12..36
+//    MFMAs; 36 independent accumulator chains (144 VGPRs) as before, 56 fragment registers instead of 40+36;
+//  * LDS rows are the natural 128 B (64 channels of one pixel); a patch row is padded to 40 (24) LDS rows so that the
+//    16-byte-piece XOR swizzle -- bits 1 and 3 of the LDS row index select one of four 32-byte bank groups, on the DMA's
+//    per-lane SOURCE address and on the transposed reads -- leaves the 8 pixel rows x 32 B of a ds_read_b64_tr_b16
+//    half-wave in 8 different bank groups for every column shift, and every fragment address is one per-lane constant
+//    XOR {0, 32, 64, 96} + an immediate.
+// Same split-K slabs / ordered reduction as above: bitwise reproducible, and bit-identical between runs.
+template <int NRH, int NCH, bool PAIRED>
+struct W16 {
+  static constexpr int PW = PAIRED ? 24 : 40;                  // LDS rows per patch row (18 / 34 of them used)
+  static constexpr int XROWS = PAIRED ? 2 * 6 * 24 : 6 * 40;   // 288 / 240 LDS rows per 64-channel half of the patch
+  static constexpr int R_HALF = 128 * 128, C_HALF = XROWS * 128;
+  static constexpr int R_INSTR = 16, C_INSTR = XROWS / 8;      // one-KiB DMA instructions per half
+  static constexpr int NINSTR = NRH * R_INSTR + NCH * C_INSTR;
+  static constexpr int NDMA = (NINSTR + 7) / 8;                // per wave (surplus -> dummy KiB)
+  static constexpr int BUF = NRH * R_HALF + NCH * C_HALF;
+  static constexpr int LDS = 2 * BUF + 1024;
+  static constexpr int WR = 2 * NRH, WC = 2 * NCH;             // waves along gradient rows / columns (32 channels each)
+  static_assert(WR * WC == 8, "eight waves");
+};
+
+template <int NRH, int NCH, bool PAIRED>
+__global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
+  using C = W16<NRH, NCH, PAIRED>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction: keep it scalar
+  const int wr = wave % C::WR, wc = wave / C::WR;
+
+  int sp, rtile, ctile;
+  if (!wgrad_block_coords(P, sp, rtile, ctile)) return;
+  sp = __builtin_amdgcn_readfirstlane(sp);
+  rtile = __builtin_amdgcn_readfirstlane(rtile);
+  ctile = __builtin_amdgcn_readfirstlane(ctile);
+  const int rch = rtile * 64 * NRH;
+  WView CS[NCH];
+  int cch[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    const int c = (ctile * NCH + h) * 64;
+    const bool first = c < P.ct[0].C;
+    CS[h] = first ? P.ct[0] : P.ct[1];
+    cch[h] = first ? c : c - P.ct[0].C;
+  }
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transposed-read lane geometry.  16x16x32 operands: lane = (k group g = lane >> 4: k = 8g .. 8g+7) x (channel
+  // lane & 15).  ds_read_b64_tr_b16: lane i of a 16-lane group ADDRESSES pixel row (i >> 2) of the group's 4 rows,
+  // channels 4 (i & 3) .. +3, and RECEIVES the four rows of channel i; two reads (rows +0..3, +4..7) = the 8 k values.
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, cq = (i16 & 3) * 8;
+  int a_off[2];                                   // dY: LDS row = ty*32 + 8g + 4j + q -> swizzle (q >> 1) | (g & 1) << 1
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int cg = (wr & 1) * 2 + cb;
+    a_off[cb] = (wr >> 1) * C::R_HALF + (8 * g + q) * 128 + ((cg ^ ((q >> 1) | ((g & 1) << 1))) << 5) + cq;
+  }
+  // X: LDS row = image * 144 + prow * PW + 8g' + (s + 4j + q); swizzle bit 0 = bit 1 of (s + 4j + q), bit 1 =
+  // bit0(g') ^ bit 3 of (s + 4j + q) ^ (prow & 1) -- the prow term and the second 16-channel block are XORs of 64 / 32
+  const int gp = PAIRED ? (g & 1) : g;
+  int b_off[3][2];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = sx + 4 * j + q;
+      const int f = ((t >> 1) & 1) | ((((gp & 1) ^ (t >> 3)) & 1) << 1);
+      const int cg = (wc & 1) * 2;
+      b_off[sx][j] = NRH * C::R_HALF + (wc >> 1) * C::C_HALF + ((PAIRED ? (g >> 1) * 144 : 0) + 8 * gp + t) * 128 +
+                     ((cg ^ f) << 5) + cq;
+    }
+
+  // ---- DMA.  One instruction = 8 LDS rows (pixels) x 128 B; lane -> row lane >> 3, 16-byte position lane & 7.  Waves
+  // 0 .. NWR-1 fetch the dY tile, the others the X patch, so every quantity except the lane's (row, position) is
+  // wave-uniform and lives in SGPRs: per instruction a scalar base (soffset), one of two per-lane constants
+  // (pixel * channel stride + swizzled piece; bit 3 of the LDS row = the instruction's parity) and a column range check.
+  constexpr int NWR = NRH * C::R_INSTR / 8;                    // waves on dY (8 instructions each)
+  constexpr int NXW = 8 - NWR;                                  // waves on X
+  constexpr int NX = (NCH * C::C_INSTR + NXW - 1) / NXW;        // X instructions per wave
+  const bool r_wave = wave < NWR;
+  const unsigned r_img = (unsigned)P.rt.H * P.rt.W * P.rt.C * 2u;
+  unsigned c_img[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) c_img[h] = (unsigned)CS[h].H * CS[h].W * CS[h].C * 2u;
+
+  auto dma = [&](int tile, int buf) {
+    // (runtime integer divisions execute on the vector ALU: bring the wave-uniform results back to SGPRs, or every
+    //  buffer resource / scalar offset below costs a waterfall loop)
+    int t = tile;
+    const int txi = __builtin_amdgcn_readfirstlane(t % P.tilesX);  t = __builtin_amdgcn_readfirstlane(t / P.tilesX);
+    const int tyi = __builtin_amdgcn_readfirstlane(t % P.tilesY);
+    const int n0 = __builtin_amdgcn_readfirstlane(t / P.tilesY) * (PAIRED ? 2 : 1);
+    const int ty0 = tyi * 4, tx0 = PAIRED ? 0 : txi * 32;
+    const int nimg = (PAIRED && n0 + 1 < P.N) ? 2 : 1;
+    // the lane-dependent constants are re-derived per tile (a dozen VALU ops) instead of living in VGPRs across the MFMA
+    // loop, where 200 registers belong to accumulators and fragments: the opaque copy keeps LICM from hoisting them
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int lx = ln >> 3;
+    const int pz = (ln & 7) ^ (((ln >> 4) & 1) << 1);           // piece ^ (bit 1 of the row) << 1
+    if (r_wave) {
+      const __amdgpu_buffer_rsrc_t rr =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(P.rt.p + (size_t)n0 * r_img), (short)0, (int)(r_img * nimg), 0x00020000);
+      const unsigned lstr = (unsigned)lx * (unsigned)(P.rt.C * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int li = wave * 8 + j;                            // instruction of the dY tile: LDS rows li*8 .. +7
+        const int h = li / C::R_INSTR, l16 = li % C::R_INSTR;
+        const int ty = l16 >> 2, c0 = (l16 & 3) * 8;            // tile row, first of the 8 columns (0..31)
+        const int img = PAIRED ? (c0 >> 4) : 0;
+        const int y = ty0 + ty, x0 = tx0 + (PAIRED ? (c0 & 15) : c0);
+        const bool rowok = y < P.H && img < nimg;
+        const unsigned so = (unsigned)img * r_img + (unsigned)(((y * P.rt.W + x0) * P.rt.C + rch + h * 64) * 2);
+        const unsigned lane_off = lstr + (unsigned)((pz ^ ((l16 & 1) << 2)) << 4);
+        const unsigned vo = (rowok && x0 + lx < P.W) ? lane_off : OOB;
+        char* dst = smem + buf * C::BUF + h * C::R_HALF + l16 * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int i2 = (wave - NWR) * NX + j;
+        if (i2 >= NCH * C::C_INSTR) break;
+        const int h = NCH == 1 ? 0 : i2 / C::C_INSTR, li = NCH == 1 ? i2 : i2 % C::C_INSTR;   // LDS rows li*8 .. +7 of half h
+        // (scalar selects: indexing CS[] with the run-time h would put the view into scratch memory)
+        const bool h1 = NCH > 1 && h == 1;
+        WView S;
+        S.p = h1 ? CS[NCH - 1].p : CS[0].p;  S.C = h1 ? CS[NCH - 1].C : CS[0].C;  S.H = h1 ? CS[NCH - 1].H : CS[0].H;
+        S.W = h1 ? CS[NCH - 1].W : CS[0].W;  S.oy = h1 ? CS[NCH - 1].oy : CS[0].oy;  S.ox = h1 ? CS[NCH - 1].ox : CS[0].ox;
+        const unsigned cimg = h1 ? c_img[NCH - 1] : c_img[0];
+        const int cchh = h1 ? cch[NCH - 1] : cch[0];
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(S.p + (size_t)n0 * cimg), (short)0, (int)(cimg * nimg), 0x00020000);
+        constexpr int IPR = C::PW / 8;                          // instructions per patch row (5 / 3)
+        const int img = PAIRED ? li / (6 * IPR) : 0, lr = PAIRED ? li % (6 * IPR) : li;
+        const int prow = lr / IPR, pc0 = (lr % IPR) * 8;        // patch row, first of the 8 patch columns
+        const int y = ty0 + prow - 1 - S.oy, x0 = tx0 + pc0 - 1 - S.ox;
+        const bool rowok = y >= 0 && y < S.H && img < nimg;
+        // scalar part: the image row (never negative once rowok); the column (x0 may be -1) stays in the lane part
+        const unsigned so = (unsigned)img * cimg + (unsigned)((y * S.W * S.C + cchh) * 2);
+        const unsigned lane_off = (unsigned)(x0 + lx) * (unsigned)(S.C * 2) + (unsigned)((pz ^ ((li & 1) << 2)) << 4);
+        const bool colok = (unsigned)(x0 + lx) < (unsigned)S.W && pc0 + lx < (PAIRED ? 18 : 34);
+        const unsigned vo = (rowok && colok) ? lane_off : OOB;
+        char* dst = smem + buf * C::BUF + NRH * C::R_HALF + h * C::C_HALF + li * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+      }
+    }
+  };
+
+  const int ngroups = PAIRED ? (P.N + 1) / 2 : P.N;
+  const int ntiles = ngroups * P.tilesY * P.tilesX;
+  const int t_begin = sp * P.tilesPerSplit;
+  const int t_end = min(t_begin + P.tilesPerSplit, ntiles);
+
+  if (t_begin < t_end) dma(t_begin, 0);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int buf = (tile - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile `tile` has landed
+    __builtin_amdgcn_s_barrier();                               // ... everyone's has; buffer buf^1 is free
+    if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
+    const char* sb = smem + buf * C::BUF;
+    auto ldA = [&](int ty, int cb) {
+      const int o = a_off[cb] + ty * 4096;
+      return tr_frag2(sb, o, o + 512);
+    };
+    auto ldB = [&](int prow, int sx, int nb) {
+      // the XOR variants (x = 0/32/64/96) of the six lane constants are formed where they are used: left to itself
+      // the compiler hoists all 24 out of the tile loop and spills them (the opaque copies forbid that; 2 VALU per read)
+      const int x = (nb ? 32 : 0) ^ ((prow & 1) ? 64 : 0);
+      int o0 = b_off[sx][0], o1 = b_off[sx][1];
+      if (x) {
+        asm volatile("" : "+v"(o0), "+v"(o1));
+        o0 ^= x;
+        o1 ^= x;
+      }
+      return tr_frag2(sb, o0 + prow * (C::PW * 128), o1 + prow * (C::PW * 128));
+    };
+    bf16x8 fa[3][2], fb[3][2];                                  // dY rows: ring of 3 (tile rows p, p-1, p-2 are live)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) fa[0][cb] = ldA(0, cb);
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) fb[sx][nb] = ldB(0, sx, nb);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        // oldest dY row first: the row fetched at the end of the previous step (r = 0) is used last
+#pragma unroll
+        for (int r = 2; r >= 0; --r) {
+          const int ty = p - r;
+          if (ty < 0 || ty > 3) continue;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              acc[r * 3 + sx][cb][nb] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ty % 3][cb], fb[sx][nb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
+        }
+        // the X fragments of the NEXT patch row replace the ones just retired (>= 8 MFMAs before their first use)
+        if (p + 1 < 6) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) fb[sx][nb] = ldB(p + 1, sx, nb);
+        }
+      }
+      // tile row p-2 is retired: its ring slot takes row p+1
+      if (p + 1 < 4) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) fa[(p + 1) % 3][cb] = ldA(p + 1, cb);
+      }
+    }
+  }
+
+  // ---- partial slab.  D of 16x16x32: column (X channel) = lane & 15, rows (dY channels) = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    float* o = P.partial + ((size_t)(sp * 9 + tap) * P.Crow) * P.Ccol;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int col = ctile * 64 * NCH + wc * 32 + nb * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rch + wr * 32 + cb * 16 + g * 4 + r;
+          o[(size_t)row * P.Ccol + col] = acc[tap][cb][nb][r];
+        }
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Many splits, few outputs (the 64-channel layers: 512 slabs of 9x64x64): one block per (row, 64 columns,
 // tap), 4 slab-lanes per output, combined in a fixed order through LDS.
 template <int TAPS>
@@ -514,6 +766,38 @@ Plan make_plan(int n, int h, int w, int crow, int ccol) {
   return p;
 }
 
+// wgrad16_kernel: 128 x 64 (crow % 128 == 0) or 64 x 128 (crow == 64, ccol % 128 == 0, wide frames) channel tiles, 4 x 32
+// pixel tiles (PAIRED: two 16-wide images), one block per CU -> 256 blocks
+inline int wgrad16_variant(int w, int crow, int ccol) {          // 0: not served; 1: <2,1,wide>; 2: <2,1,paired>; 3: <1,2,wide>
+  if (crow % 128 == 0) return w <= 16 ? 2 : 1;
+  if (crow == 64 && ccol % 128 == 0 && w > 16) return 3;
+  return 0;
+}
+inline Plan make_plan16(int n, int h, int w, int crow, int ccol) {
+  Plan p;
+  const int v = wgrad16_variant(w, crow, ccol);
+  p.tilesX = v == 2 ? 1 : cdiv(w, 32);
+  p.tilesY = cdiv(h, 4);
+  p.nR = v == 3 ? crow / 64 : crow / 128;
+  p.nC = v == 3 ? ccol / 128 : ccol / 64;
+  const long long ntiles = (long long)(v == 2 ? (n + 1) / 2 : n) * p.tilesY * p.tilesX;
+  long long want = 256 / ((long long)p.nR * p.nC);
+  if (want < 1) want = 1;
+  if (want > ntiles) want = ntiles;
+  p.tilesPerSplit = (int)cdiv64(ntiles, want);
+  p.split = (int)cdiv64(ntiles, p.tilesPerSplit);
+  p.bytes = (size_t)p.split * 9 * crow * ccol * sizeof(float);
+  return p;
+}
+
+template <int NRH, int NCH, bool PAIRED>
+void launch16(const WgradParams& P, long long blocks, hipStream_t s) {
+  using C = W16<NRH, NCH, PAIRED>;
+  auto kern = wgrad16_kernel<NRH, NCH, PAIRED>;
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
+}
+
 template <typename T, int TAPS>
 int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_out, int kclass, hipStream_t s) {
   using C = WCfg<T, TAPS>;
@@ -528,15 +812,28 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
     blocks = 8LL * P.xcd_chunk;
   }
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Crow * P.Ccol * TAPS;
+  const char impl = unet_tuning().wgrad_impl;   // UNET_WGRAD_IMPL: 0 register-staged, 1 the 32x32x16 LDS-DMA kernel, 2 that without reuse
+  int split_used = pl.split;
   {
     // algorithmic bytes: both activation tensors once + the fp32 gradient once (split-K slabs are overhead, not counted)
     const double alg_bytes = (double)P.N * P.H * P.W * ((double)P.Crow + P.Ccol * (TAPS == 9 ? 1.0 : 4.0)) * sizeof(T) +
                              4.0 * TAPS * rows_out * cols_out;
     ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)",
                    alg_bytes);
-    const char impl = unet_tuning().wgrad_impl;                 // UNET_WGRAD_IMPL: '0' = register-staged kernel
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-      if (impl != '0') {
+      const int v16 = (impl == 0 || impl == '3') ? wgrad16_variant(P.W, P.Crow, P.Ccol) : 0;
+      if (v16) {
+        const Plan p16 = make_plan16(P.N, P.H, P.W, P.Crow, P.Ccol);
+        P.tilesX = p16.tilesX; P.tilesY = p16.tilesY; P.nR = p16.nR; P.nC = p16.nC;
+        P.split = p16.split; P.tilesPerSplit = p16.tilesPerSplit;
+        split_used = p16.split;
+        long long b16 = (long long)p16.split * p16.nR * p16.nC;
+        P.xcd_chunk = 0;
+        if (unet_tuning().wgrad_xcd != '0' && b16 >= 16) { P.xcd_chunk = (int)cdiv64(b16, 8); b16 = 8LL * P.xcd_chunk; }
+        if (v16 == 1) launch16<2, 1, false>(P, b16, s);
+        else if (v16 == 2) launch16<2, 1, true>(P, b16, s);
+        else launch16<1, 2, false>(P, b16, s);
+      } else if (impl != '0') {
         unet_set_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<true>), WDma::LDS);
         unet_set_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<false>), WDma::LDS);
         if (impl == '2')                                        // "2": every tap re-reads its X fragment
@@ -551,14 +848,14 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
     }
     int32_t rc = unet_check_launch("wgrad_kernel");
     if (rc) return rc;
-    if (pl.split >= 16) {
+    if (split_used >= 16) {
       const long long rb = (long long)rows_out * ((cols_out + 63) / 64) * TAPS;
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel<TAPS>, dim3((unsigned)rb), dim3(256), 0, s, (const float*)P.partial,
-                         out, pl.split, P.Crow, P.Ccol, rows_out, cols_out);
+                         out, split_used, P.Crow, P.Ccol, rows_out, cols_out);
     } else {
       const long long total = (long long)rows_out * cols_out;
       const int rb = (int)std::min<long long>(cdiv64(total, 256), 4096);
-      hipLaunchKernelGGL(wgrad_reduce_kernel<TAPS>, dim3(rb), dim3(256), 0, s, (const float*)P.partial, out, pl.split,
+      hipLaunchKernelGGL(wgrad_reduce_kernel<TAPS>, dim3(rb), dim3(256), 0, s, (const float*)P.partial, out, split_used,
                          P.Crow, P.Ccol, rows_out, cols_out);
     }
   }
@@ -570,7 +867,10 @@ inline int pad64(int c) { return (c + 63) / 64 * 64; }
 }  // namespace
 
 extern "C" size_t unet_conv3x3_wgrad_workspace(int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
-  return make_plan<9>(n, h, w, pad64(c_out), pad64(c_in)).bytes;
+  size_t bytes = make_plan<9>(n, h, w, pad64(c_out), pad64(c_in)).bytes;
+  if (wgrad16_variant(w, pad64(c_out), pad64(c_in)))
+    bytes = std::max(bytes, make_plan16(n, h, w, pad64(c_out), pad64(c_in)).bytes);
+  return bytes;
 }
 
 extern "C" int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32_t w, const unet_view src[2],
@@ -587,8 +887,8 @@ extern "C" int32_t unet_conv3x3_wgrad(int32_t dtype, int32_t n, int32_t h, int32
                src[1].ptr ? src[1].c : 0);
   UNET_REQUIRE(c_in_param <= ctot, UNET_ERR_BAD_ARG, "unet_conv3x3_wgrad: c_in_param %d > %d", c_in_param, ctot);
   const Plan pl = make_plan<9>(n, h, w, c_out, ctot);
-  UNET_REQUIRE(workspace_bytes >= pl.bytes, UNET_ERR_WORKSPACE, "unet_conv3x3_wgrad: workspace %zu < %zu",
-               workspace_bytes, pl.bytes);
+  const size_t need = unet_conv3x3_wgrad_workspace(n, h, w, ctot, c_out);
+  UNET_REQUIRE(workspace_bytes >= need, UNET_ERR_WORKSPACE, "unet_conv3x3_wgrad: workspace %zu < %zu", workspace_bytes, need);
   WgradParams P{};
 #ifdef PDMA_STAMPS
   P.debug = g_wgrad_debug;
