@@ -289,6 +289,12 @@ __device__ inline bf16x8 tr_frag2(const char* base, int off0, int off1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+#ifdef PDMA_STAMPS
+#define WG_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wg_st[i] += t_ - wg_prev; wg_prev = t_; }
+#else
+#define WG_STAMP(i)
+#endif
+
 template <bool REUSE>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) {
   using C = WDma;
@@ -386,9 +392,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
 #ifdef PDMA_STAMPS
   unsigned long long wg_st[4] = {0, 0, 0, 0}, wg_prev = __builtin_amdgcn_s_memtime();
   const unsigned long long wg_t0 = wg_prev, wg_r0 = __builtin_amdgcn_s_memrealtime();
-#define WG_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wg_st[i] += t_ - wg_prev; wg_prev = t_; }
-#else
-#define WG_STAMP(i)
 #endif
   if (t_begin < t_end) dma(t_begin, 0);
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -468,32 +471,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
 // wgrad16_kernel<NRH, NCH, PAIRED> (round 3): the bf16 conv3x3 weight gradient on v_mfma_f32_16x16x32_bf16.
 //
 // Why: the 32x32x16 kernel above ran at 1.23-1.58 GHz in-kernel (profiles/r02_wgrad_stamps.txt) -- the chip holds a
-// higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7) -- and ~36 % of a tile went to its ten
-// one-KiB LDS-DMA issues per wave.  Here:
+// higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7; stamped here: 1.76-1.90 GHz) -- and
+// ~36 % of a tile went to its ten one-KiB LDS-DMA issues per wave.  Here:
 //  * one 512-thread block per CU owns 128 x 64 (NRH=2, NCH=1) or 64 x 128 (1, 2) gradient channels x 9 taps: the X patch
 //    (or the dY tile) is staged once for twice the MFMAs -- 62 instead of 78 KiB of LDS-DMA per 18.9 MFLOP;
 //  * K = 32 pixels per MFMA = one 32-pixel tile ROW (tile 4 x 32; PAIRED, W <= 16: 16 pixels of image n + 16 of image
 //    n+1), so the X fragment of (patch row p, column shift s) still serves the three (tile row, tap row) pairs with
 //    ty + r = p; the loop walks PATCH rows: per row 6 X fragments + 2 dY fragments (a 4-slot ring of dY rows), 12..36
-//    MFMAs; 36 independent accumulator chains (144 VGPRs) as before, 56 fragment registers instead of 40+36;
-//  * LDS rows are the natural 128 B (64 channels of one pixel); a patch row is padded to 40 (24) LDS rows so that the
-//    16-byte-piece XOR swizzle -- bits 1 and 3 of the LDS row index select one of four 32-byte bank groups, on the DMA's
-//    per-lane SOURCE address and on the transposed reads -- leaves the 8 pixel rows x 32 B of a ds_read_b64_tr_b16
-//    half-wave in 8 different bank groups for every column shift, and every fragment address is one per-lane constant
-//    XOR {0, 32, 64, 96} + an immediate.
-// Same split-K slabs / ordered reduction as above: bitwise reproducible, and bit-identical between runs.
+//    MFMAs; 36 independent accumulator chains (144 VGPRs) as before;
+//  * LDS rows are the natural 128 B (64 channels of one pixel); a patch row is padded to PW = 48 / 40 / 24 LDS rows so
+//    that the 16-byte-piece XOR swizzle -- bits 1 and 3 of the LDS row index select one of four 32-byte bank groups, on
+//    the DMA's per-lane SOURCE address and on the transposed reads -- leaves the 8 pixel rows x 32 B of a
+//    ds_read_b64_tr_b16 half-wave in 8 different bank groups for every column shift (SQ_LDS_BANK_CONFLICT = 0), and
+//    every fragment address is one of 12 (PW/8 even) or 24 per-lane constants + an immediate: NO address arithmetic in
+//    the loop.  That matters on this MFMA shape: a 16-cycle MFMA holds the SIMD's vector issue for 8 cycles, so two
+//    waves per SIMD leave 8 cycles per MFMA for everything else; the first version (2 VALU per fragment read) was
+//    vector-ISSUE-bound (SQ counters: 1.43 VALU per MFMA, 54 % MFMA busy);
+//  * the two waves of a SIMD issue their LDS-DMAs at opposite ends of a tile (see the loop).
+// Same split-K slabs / ordered reduction as above: bitwise reproducible, and bit-identical to the 32x32x16 kernel's sums
+// only up to fp32 summation order (K is walked in a different order).
 template <int NRH, int NCH, bool PAIRED>
 struct W16 {
-  static constexpr int PW = PAIRED ? 24 : 40;                  // LDS rows per patch row (18 / 34 of them used)
-  static constexpr int XROWS = PAIRED ? 2 * 6 * 24 : 6 * 40;   // 288 / 240 LDS rows per 64-channel half of the patch
+  static constexpr int PW = PAIRED ? 24 : (NCH == 1 ? 48 : 40); // LDS rows per patch row (18 / 34 of them used)
+  static constexpr bool PX = ((PW / 8) & 1) != 0;               // bit 3 of the LDS row flips with the patch row
+  static constexpr int IMGROWS = 6 * PW;                        // LDS rows of one image's patch
+  static constexpr int XROWS = (PAIRED ? 2 : 1) * IMGROWS;
   static constexpr int R_HALF = 128 * 128, C_HALF = XROWS * 128;
-  static constexpr int R_INSTR = 16, C_INSTR = XROWS / 8;      // one-KiB DMA instructions per half
-  static constexpr int NINSTR = NRH * R_INSTR + NCH * C_INSTR;
-  static constexpr int NDMA = (NINSTR + 7) / 8;                // per wave (surplus -> dummy KiB)
+  static constexpr int IPR = PAIRED ? 3 : 5;                    // DMA pieces (8 LDS rows) per patch row that hold data
+  static constexpr int R_INSTR = 16, C_INSTR = (PAIRED ? 2 : 1) * 6 * IPR;   // one-KiB DMA instructions per half
   static constexpr int BUF = NRH * R_HALF + NCH * C_HALF;
   static constexpr int LDS = 2 * BUF + 1024;
-  static constexpr int WR = 2 * NRH, WC = 2 * NCH;             // waves along gradient rows / columns (32 channels each)
+  static constexpr int WR = 2 * NRH, WC = 2 * NCH;              // waves along gradient rows / columns (32 channels each)
   static_assert(WR * WC == 8, "eight waves");
+  static_assert(LDS <= 160 * 1024, "LDS");
+  static_assert(5 * PW * 128 + 12 * 128 + 512 < 65536, "fragment offsets are 16-bit immediates");
 };
 
 template <int NRH, int NCH, bool PAIRED>
@@ -540,25 +551,29 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     const int cg = (wr & 1) * 2 + cb;
     a_off[cb] = (wr >> 1) * C::R_HALF + (8 * g + q) * 128 + ((cg ^ ((q >> 1) | ((g & 1) << 1))) << 5) + cq;
   }
-  // X: LDS row = image * 144 + prow * PW + 8g' + (s + 4j + q); swizzle bit 0 = bit 1 of (s + 4j + q), bit 1 =
-  // bit0(g') ^ bit 3 of (s + 4j + q) ^ (prow & 1) -- the prow term and the second 16-channel block are XORs of 64 / 32
+  // X: LDS row = image * IMGROWS + prow * PW + 8g' + (s + 4j + q); swizzle bit 0 = bit 1 of (s + 4j + q), bit 1 =
+  // bit0(g') ^ bit 3 of (s + 4j + q) [^ (prow & 1) when PW/8 is odd: a second set of constants for the odd patch rows]
   const int gp = PAIRED ? (g & 1) : g;
-  int b_off[3][2];
+  int b_off[C::PX ? 2 : 1][3][2][2];              // [patch-row parity][shift][read][16-channel block]
 #pragma unroll
-  for (int sx = 0; sx < 3; ++sx)
+  for (int par = 0; par < (C::PX ? 2 : 1); ++par)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int t = sx + 4 * j + q;
-      const int f = ((t >> 1) & 1) | ((((gp & 1) ^ (t >> 3)) & 1) << 1);
-      const int cg = (wc & 1) * 2;
-      b_off[sx][j] = NRH * C::R_HALF + (wc >> 1) * C::C_HALF + ((PAIRED ? (g >> 1) * 144 : 0) + 8 * gp + t) * 128 +
-                     ((cg ^ f) << 5) + cq;
-    }
+    for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int t = sx + 4 * j + q;
+          const int f = ((t >> 1) & 1) | ((((gp & 1) ^ (t >> 3) ^ par) & 1) << 1);
+          const int cg = (wc & 1) * 2 + nb;
+          b_off[par][sx][j][nb] = NRH * C::R_HALF + (wc >> 1) * C::C_HALF +
+                                  ((PAIRED ? (g >> 1) * C::IMGROWS : 0) + 8 * gp + t) * 128 + ((cg ^ f) << 5) + cq;
+        }
 
   // ---- DMA.  One instruction = 8 LDS rows (pixels) x 128 B; lane -> row lane >> 3, 16-byte position lane & 7.  Waves
   // 0 .. NWR-1 fetch the dY tile, the others the X patch, so every quantity except the lane's (row, position) is
-  // wave-uniform and lives in SGPRs: per instruction a scalar base (soffset), one of two per-lane constants
-  // (pixel * channel stride + swizzled piece; bit 3 of the LDS row = the instruction's parity) and a column range check.
+  // wave-uniform and lives in SGPRs: per instruction a scalar base (soffset), a per-lane constant (pixel * channel
+  // stride + swizzled piece; bit 3 of the LDS row = a property of the instruction) and a column range check.
   constexpr int NWR = NRH * C::R_INSTR / 8;                    // waves on dY (8 instructions each)
   constexpr int NXW = 8 - NWR;                                  // waves on X
   constexpr int NX = (NCH * C::C_INSTR + NXW - 1) / NXW;        // X instructions per wave
@@ -568,17 +583,25 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
 #pragma unroll
   for (int h = 0; h < NCH; ++h) c_img[h] = (unsigned)CS[h].H * CS[h].W * CS[h].C * 2u;
 
-  auto dma = [&](int tile, int buf) {
-    // (runtime integer divisions execute on the vector ALU: bring the wave-uniform results back to SGPRs, or every
-    //  buffer resource / scalar offset below costs a waterfall loop)
-    int t = tile;
-    const int txi = __builtin_amdgcn_readfirstlane(t % P.tilesX);  t = __builtin_amdgcn_readfirstlane(t / P.tilesX);
-    const int tyi = __builtin_amdgcn_readfirstlane(t % P.tilesY);
-    const int n0 = __builtin_amdgcn_readfirstlane(t / P.tilesY) * (PAIRED ? 2 : 1);
-    const int ty0 = tyi * 4, tx0 = PAIRED ? 0 : txi * 32;
+  // the tile being FETCHED: (image [pair], tile row, tile column), advanced by scalar compares -- no divisions in the loop
+  int d_txi, d_tyi, d_n;
+  {
+    int t = sp * P.tilesPerSplit;
+    d_txi = __builtin_amdgcn_readfirstlane(t % P.tilesX);  t = __builtin_amdgcn_readfirstlane(t / P.tilesX);
+    d_tyi = __builtin_amdgcn_readfirstlane(t % P.tilesY);
+    d_n = __builtin_amdgcn_readfirstlane(t / P.tilesY);
+  }
+  auto next_tile = [&]() {
+    if (++d_txi == P.tilesX) {
+      d_txi = 0;
+      if (++d_tyi == P.tilesY) { d_tyi = 0; ++d_n; }
+    }
+  };
+  auto dma = [&](int buf) {
+    const int n0 = d_n * (PAIRED ? 2 : 1), ty0 = d_tyi * 4, tx0 = PAIRED ? 0 : d_txi * 32;
     const int nimg = (PAIRED && n0 + 1 < P.N) ? 2 : 1;
-    // the lane-dependent constants are re-derived per tile (a dozen VALU ops) instead of living in VGPRs across the MFMA
-    // loop, where 200 registers belong to accumulators and fragments: the opaque copy keeps LICM from hoisting them
+    // the lane-dependent constants are re-derived per tile (a few VALU ops) instead of living in VGPRs across the MFMA
+    // loop: the opaque copy keeps LICM from hoisting them
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int lx = ln >> 3;
@@ -587,6 +610,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
       const __amdgpu_buffer_rsrc_t rr =
           __builtin_amdgcn_make_buffer_rsrc((void*)(P.rt.p + (size_t)n0 * r_img), (short)0, (int)(r_img * nimg), 0x00020000);
       const unsigned lstr = (unsigned)lx * (unsigned)(P.rt.C * 2);
+      const unsigned lane_off0 = lstr + (unsigned)(pz << 4), lane_off1 = lstr + (unsigned)((pz ^ 4) << 4);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int li = wave * 8 + j;                            // instruction of the dY tile: LDS rows li*8 .. +7
@@ -596,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
         const int y = ty0 + ty, x0 = tx0 + (PAIRED ? (c0 & 15) : c0);
         const bool rowok = y < P.H && img < nimg;
         const unsigned so = (unsigned)img * r_img + (unsigned)(((y * P.rt.W + x0) * P.rt.C + rch + h * 64) * 2);
-        const unsigned lane_off = lstr + (unsigned)((pz ^ ((l16 & 1) << 2)) << 4);
+        const unsigned lane_off = (j & 1) ? lane_off1 : lane_off0;        // (bit 3 of the LDS row = l16 & 1 = j & 1)
         const unsigned vo = (rowok && x0 + lx < P.W) ? lane_off : OOB;
         char* dst = smem + buf * C::BUF + h * C::R_HALF + l16 * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
@@ -606,7 +630,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
       for (int j = 0; j < NX; ++j) {
         const int i2 = (wave - NWR) * NX + j;
         if (i2 >= NCH * C::C_INSTR) break;
-        const int h = NCH == 1 ? 0 : i2 / C::C_INSTR, li = NCH == 1 ? i2 : i2 % C::C_INSTR;   // LDS rows li*8 .. +7 of half h
+        const int h = NCH == 1 ? 0 : i2 / C::C_INSTR, li = NCH == 1 ? i2 : i2 % C::C_INSTR;
         // (scalar selects: indexing CS[] with the run-time h would put the view into scratch memory)
         const bool h1 = NCH > 1 && h == 1;
         WView S;
@@ -616,17 +640,17 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
         const int cchh = h1 ? cch[NCH - 1] : cch[0];
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(S.p + (size_t)n0 * cimg), (short)0, (int)(cimg * nimg), 0x00020000);
-        constexpr int IPR = C::PW / 8;                          // instructions per patch row (5 / 3)
-        const int img = PAIRED ? li / (6 * IPR) : 0, lr = PAIRED ? li % (6 * IPR) : li;
-        const int prow = lr / IPR, pc0 = (lr % IPR) * 8;        // patch row, first of the 8 patch columns
+        const int img = PAIRED ? li / (6 * C::IPR) : 0, lr = PAIRED ? li % (6 * C::IPR) : li;
+        const int prow = lr / C::IPR, pc0 = (lr % C::IPR) * 8;  // patch row, first of the 8 patch columns
+        const int row0 = img * C::IMGROWS + prow * C::PW + pc0; // first LDS row of the piece
         const int y = ty0 + prow - 1 - S.oy, x0 = tx0 + pc0 - 1 - S.ox;
         const bool rowok = y >= 0 && y < S.H && img < nimg;
         // scalar part: the image row (never negative once rowok); the column (x0 may be -1) stays in the lane part
         const unsigned so = (unsigned)img * cimg + (unsigned)((y * S.W * S.C + cchh) * 2);
-        const unsigned lane_off = (unsigned)(x0 + lx) * (unsigned)(S.C * 2) + (unsigned)((pz ^ ((li & 1) << 2)) << 4);
+        const unsigned lane_off = (unsigned)(x0 + lx) * (unsigned)(S.C * 2) + (unsigned)((pz ^ (((row0 >> 3) & 1) << 2)) << 4);
         const bool colok = (unsigned)(x0 + lx) < (unsigned)S.W && pc0 + lx < (PAIRED ? 18 : 34);
         const unsigned vo = (rowok && colok) ? lane_off : OOB;
-        char* dst = smem + buf * C::BUF + NRH * C::R_HALF + h * C::C_HALF + li * 1024;
+        char* dst = smem + buf * C::BUF + NRH * C::R_HALF + h * C::C_HALF + row0 * 128;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
       }
     }
@@ -637,30 +661,37 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
   const int t_begin = sp * P.tilesPerSplit;
   const int t_end = min(t_begin + P.tilesPerSplit, ntiles);
 
-  if (t_begin < t_end) dma(t_begin, 0);
+#ifdef PDMA_STAMPS
+  unsigned long long wg_st[4] = {0, 0, 0, 0}, wg_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long wg_t0 = wg_prev, wg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (t_begin < t_end) dma(0);
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int buf = (tile - t_begin) & 1;
+    WG_STAMP(3)
+    next_tile();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile `tile` has landed
+    WG_STAMP(0)
     __builtin_amdgcn_s_barrier();                               // ... everyone's has; buffer buf^1 is free
-    if (tile + 1 < t_end) dma(tile + 1, buf ^ 1);
-    const char* sb = smem + buf * C::BUF;
+    WG_STAMP(1)
+    // The next tile's DMAs: a wave in its burst of 8-10 one-KiB issues (140-250 cycles EACH beside the partner's MFMAs
+    // and fragment reads, stamped) feeds no MFMAs.  The two waves of a SIMD (w, w + 4) therefore issue at opposite ends
+    // of a tile -- the X waves right here, before their MFMAs, the dY waves after theirs -- so that one of the two
+    // always has MFMAs to issue (stamps: the earlier the dY waves issued, the more the two bursts overlapped).
+    const bool more = tile + 1 < t_end;
+#ifndef W16_NO_DMA
+    if (more && !r_wave) { dma(buf ^ 1); WG_STAMP(2) }
+#endif
+    const char* sb = smem;                                      // (a_off / b_off carry the buffer's offset)
     auto ldA = [&](int ty, int cb) {
       const int o = a_off[cb] + ty * 4096;
       return tr_frag2(sb, o, o + 512);
     };
     auto ldB = [&](int prow, int sx, int nb) {
-      // the XOR variants (x = 0/32/64/96) of the six lane constants are formed where they are used: left to itself
-      // the compiler hoists all 24 out of the tile loop and spills them (the opaque copies forbid that; 2 VALU per read)
-      const int x = (nb ? 32 : 0) ^ ((prow & 1) ? 64 : 0);
-      int o0 = b_off[sx][0], o1 = b_off[sx][1];
-      if (x) {
-        asm volatile("" : "+v"(o0), "+v"(o1));
-        o0 ^= x;
-        o1 ^= x;
-      }
-      return tr_frag2(sb, o0 + prow * (C::PW * 128), o1 + prow * (C::PW * 128));
+      const int par = C::PX ? (prow & 1) : 0;
+      return tr_frag2(sb, b_off[par][sx][0][nb] + prow * (C::PW * 128), b_off[par][sx][1][nb] + prow * (C::PW * 128));
     };
-    bf16x8 fa[3][2], fb[3][2];                                  // dY rows: ring of 3 (tile rows p, p-1, p-2 are live)
+    bf16x8 fa[4][2], fb[3][2];                                  // dY rows: ring of 4 (rows p, p-1, p-2 live, p+1 in flight)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) fa[0][cb] = ldA(0, cb);
 #pragma unroll
@@ -671,7 +702,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     for (int p = 0; p < 6; ++p) {
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx) {
-        // oldest dY row first: the row fetched at the end of the previous step (r = 0) is used last
+        // oldest dY row first: the most recently fetched one (r = 0) is used last
 #pragma unroll
         for (int r = 2; r >= 0; --r) {
           const int ty = p - r;
@@ -681,22 +712,47 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
               acc[r * 3 + sx][cb][nb] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ty % 3][cb], fb[sx][nb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ty & 3][cb], fb[sx][nb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
         }
-        // the X fragments of the NEXT patch row replace the ones just retired (>= 8 MFMAs before their first use)
+        // the X fragments of the NEXT patch row replace the ones just retired, >= 8 MFMAs before their first use.  The
+        // sched_barriers pin that distance: left alone hipcc sinks every ds_read to just above its first MFMA and
+        // waits for it there (lgkmcnt(0..2) every two MFMAs: a wave alone on its SIMD ran at half the MFMA rate)
+        __builtin_amdgcn_sched_barrier(0);
         if (p + 1 < 6) {
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) fb[sx][nb] = ldB(p + 1, sx, nb);
         }
-      }
-      // tile row p-2 is retired: its ring slot takes row p+1
-      if (p + 1 < 4) {
+        if (sx == 0 && p + 1 < 4) {                             // dY row p+1 into the ring slot of the retired row p-3
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) fa[(p + 1) % 3][cb] = ldA(p + 1, cb);
+          for (int cb = 0; cb < 2; ++cb) fa[(p + 1) & 3][cb] = ldA(p + 1, cb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+#ifndef W16_NO_DMA
+    if (more && r_wave) { WG_STAMP(3) dma(buf ^ 1); WG_STAMP(2) }
+#endif
+    // the fragment addresses move to the other buffer IN PLACE (a second set of registers does not fit beside 200
+    // accumulator / fragment registers)
+    {
+      const int delta = buf ? -C::BUF : C::BUF;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) a_off[cb] += delta;
+#pragma unroll
+      for (int par = 0; par < (C::PX ? 2 : 1); ++par)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) b_off[par][sx][j][nb] += delta;
     }
   }
 
+#ifdef PDMA_STAMPS
+  WG_STAMP(3)
+  const unsigned long long wg_e0 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- partial slab.  D of 16x16x32: column (X channel) = lane & 15, rows (dY channels) = (lane >> 4) * 4 + reg
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
@@ -714,6 +770,16 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PDMA_STAMPS
+  if (P.debug && lane == 0 && blockIdx.x < 256) {
+    unsigned long long* o = (unsigned long long*)P.debug + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int i = 0; i < 4; ++i) o[i] = wg_st[i];
+    o[4] = (unsigned long long)(t_end - t_begin);
+    o[5] = ((__builtin_amdgcn_s_memtime() - wg_t0) << 20) / (__builtin_amdgcn_s_memrealtime() - wg_r0 + 1);
+    o[6] = __builtin_amdgcn_s_memtime() - wg_e0;               // partial-slab stores, drained
+    o[7] = __builtin_amdgcn_s_memtime() - wg_t0;
+  }
+#endif
 }
 
 // Many splits, few outputs (the 64-channel layers: 512 slabs of 9x64x64): one block per (row, 64 columns,

@@ -38,15 +38,25 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
-    d = dbg.view(512, 4, 8).cpu().double()
+    new = os.environ.get("UNET_WGRAD_IMPL", "") in ("", "3") and (co % 128 == 0 or (co == 64 and ci % 128 == 0 and w > 16))
+    d = (dbg.view(256, 8, 8) if new else dbg.view(512, 4, 8)).cpu().double()
     d = d[d[:, 0, 4] > 0]
     tiles = d[:, :, 4].clamp(min=1)
     clock = float(d[:, :, 5].median()) / 2 ** 20 * 0.1
-    names = ["vmcnt(0) wait", "barrier", "dma issue (10/wave)", "fragment reads + 72 mfma"]
-    per = [float((d[:, :, i] / tiles).mean()) for i in range(4)]
-    print(f"wgrad n={n} {ci}->{co} {h}x{w}: {us:.1f} us/launch incl. reduce (stamped), blocks {d.shape[0]}, tiles/block "
-          f"{float(tiles.mean()):.1f}, in-kernel clock {clock:.2f} GHz")
-    print("  per tile: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, per)) + f"   total {sum(per):.0f} cyc (ideal MFMA 2304)")
+    names = ["vmcnt(0) wait", "barrier", "dma issue", "fragment reads + mfma"]
+    print(f"wgrad n={n} {ci}->{co} {h}x{w} ({'wgrad16_kernel' if new else 'wgrad_dma_kernel'}): {us:.1f} us/launch incl. reduce "
+          f"(stamped), blocks {d.shape[0]}, tiles/block {float(tiles.mean()):.1f}, in-kernel clock {clock:.2f} GHz")
+    groups = [("all waves", slice(None))] if not new else [("dY waves (DMA mid-tile)", slice(0, 4)), ("X waves (DMA at tile start)", slice(4, 8))]
+    if new and co == 64:
+        groups = [("dY waves", slice(0, 2)), ("X waves", slice(2, 8))]
+    for label, sl in groups:
+        per = [float((d[:, sl, i] / tiles[:, sl]).mean()) for i in range(4)]
+        ideal = 2304
+        print(f"  {label}: per tile: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, per)) +
+              f"   total {sum(per):.0f} cyc (ideal MFMA {ideal} per wave, {2 * ideal} per SIMD)")
+    if new:
+        print(f"  partial-slab stores (drained): {float(d[:, :, 6].mean()):.0f} cyc; kernel body {float(d[:, :, 7].mean()):.0f} cyc "
+              f"= {float(d[:, :, 7].mean()) / clock / 1e3:.1f} us at the in-kernel clock")
 
 
 if __name__ == "__main__":
