@@ -570,14 +570,21 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
                                   ((PAIRED ? (g >> 1) * C::IMGROWS : 0) + 8 * gp + t) * 128 + ((cg ^ f) << 5) + cq;
         }
 
-  // ---- DMA.  One instruction = 8 LDS rows (pixels) x 128 B; lane -> row lane >> 3, 16-byte position lane & 7.  Waves
-  // 0 .. NWR-1 fetch the dY tile, the others the X patch, so every quantity except the lane's (row, position) is
-  // wave-uniform and lives in SGPRs: per instruction a scalar base (soffset), a per-lane constant (pixel * channel
-  // stride + swizzled piece; bit 3 of the LDS row = a property of the instruction) and a column range check.
-  constexpr int NWR = NRH * C::R_INSTR / 8;                    // waves on dY (8 instructions each)
-  constexpr int NXW = 8 - NWR;                                  // waves on X
-  constexpr int NX = (NCH * C::C_INSTR + NXW - 1) / NXW;        // X instructions per wave
-  const bool r_wave = wave < NWR;
+  // ---- DMA.  One instruction (piece) = 8 LDS rows (pixels) x 128 B; lane -> row lane >> 3, 16-byte position lane & 7.
+  // A piece belongs to one wave, so every quantity except the lane's (row, position) is wave-uniform and lives in SGPRs:
+  // per piece a scalar base (soffset), a per-lane constant (pixel * channel stride + swizzled piece; bit 3 of the LDS row
+  // = a property of the piece) and a column range check.
+  // The two waves of a SIMD (w, w + 4) issue their pieces at opposite ends of a tile (see the loop): the EARLY waves
+  // (4-7) before their MFMAs -- which they therefore start late -- the LATE waves (0-3) after theirs.  The early waves
+  // take fewer pieces (NE each, from the end of the list), so that both waves of a SIMD reach the end of the tile
+  // together (W16_NE: stamped / timed at 4, 5, 6, 8)
+#ifndef W16_NE
+#define W16_NE 8
+#endif
+  constexpr int NT = NRH * C::R_INSTR + NCH * C::C_INSTR;      // pieces per tile: 62 (128x64 wide), 68 (paired), 76 (64x128)
+  constexpr int NE = W16_NE;
+  constexpr int NLATE = (NT - 4 * NE + 3) / 4;
+  const bool late_wave = wave < 4;
   const unsigned r_img = (unsigned)P.rt.H * P.rt.W * P.rt.C * 2u;
   unsigned c_img[NCH];
 #pragma unroll
@@ -606,52 +613,60 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     asm volatile("" : "+v"(ln));
     const int lx = ln >> 3;
     const int pz = (ln & 7) ^ (((ln >> 4) & 1) << 1);           // piece ^ (bit 1 of the row) << 1
-    if (r_wave) {
-      const __amdgpu_buffer_rsrc_t rr =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(P.rt.p + (size_t)n0 * r_img), (short)0, (int)(r_img * nimg), 0x00020000);
-      const unsigned lstr = (unsigned)lx * (unsigned)(P.rt.C * 2);
-      const unsigned lane_off0 = lstr + (unsigned)(pz << 4), lane_off1 = lstr + (unsigned)((pz ^ 4) << 4);
+    auto x_piece = [&](int i2) {                                // piece i2 of the X patch (both halves counted through)
+      const int h = NCH == 1 ? 0 : i2 / C::C_INSTR, li = NCH == 1 ? i2 : i2 % C::C_INSTR;
+      // (scalar selects: indexing CS[] with the run-time h would put the view into scratch memory)
+      const bool h1 = NCH > 1 && h == 1;
+      WView S;
+      S.p = h1 ? CS[NCH - 1].p : CS[0].p;  S.C = h1 ? CS[NCH - 1].C : CS[0].C;  S.H = h1 ? CS[NCH - 1].H : CS[0].H;
+      S.W = h1 ? CS[NCH - 1].W : CS[0].W;  S.oy = h1 ? CS[NCH - 1].oy : CS[0].oy;  S.ox = h1 ? CS[NCH - 1].ox : CS[0].ox;
+      const unsigned cimg = h1 ? c_img[NCH - 1] : c_img[0];
+      const int cchh = h1 ? cch[NCH - 1] : cch[0];
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(S.p + (size_t)n0 * cimg), (short)0, (int)(cimg * nimg), 0x00020000);
+      const int img = PAIRED ? li / (6 * C::IPR) : 0, lr = PAIRED ? li % (6 * C::IPR) : li;
+      const int prow = lr / C::IPR, pc0 = (lr % C::IPR) * 8;    // patch row, first of the 8 patch columns
+      const int row0 = img * C::IMGROWS + prow * C::PW + pc0;   // first LDS row of the piece
+      const int y = ty0 + prow - 1 - S.oy, x0 = tx0 + pc0 - 1 - S.ox;
+      const bool rowok = y >= 0 && y < S.H && img < nimg;
+      // scalar part: the image row (never negative once rowok); the column (x0 may be -1) stays in the lane part
+      const unsigned so = (unsigned)img * cimg + (unsigned)((y * S.W * S.C + cchh) * 2);
+      const unsigned lane_off = (unsigned)(x0 + lx) * (unsigned)(S.C * 2) + (unsigned)((pz ^ (((row0 >> 3) & 1) << 2)) << 4);
+      const bool colok = (unsigned)(x0 + lx) < (unsigned)S.W && pc0 + lx < (PAIRED ? 18 : 34);
+      const unsigned vo = (rowok && colok) ? lane_off : OOB;
+      char* dst = smem + buf * C::BUF + NRH * C::R_HALF + h * C::C_HALF + row0 * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(P.rt.p + (size_t)n0 * r_img), (short)0, (int)(r_img * nimg), 0x00020000);
+    const unsigned lstr = (unsigned)lx * (unsigned)(P.rt.C * 2);
+    auto y_piece = [&](int li) {                                // piece li of the dY tile: LDS rows li*8 .. +7
+      const int h = li / C::R_INSTR, l16 = li % C::R_INSTR;
+      const int ty = l16 >> 2, c0 = (l16 & 3) * 8;              // tile row, first of the 8 columns (0..31)
+      const int img = PAIRED ? (c0 >> 4) : 0;
+      const int y = ty0 + ty, x0 = tx0 + (PAIRED ? (c0 & 15) : c0);
+      const bool rowok = y < P.H && img < nimg;
+      const unsigned so = (unsigned)img * r_img + (unsigned)(((y * P.rt.W + x0) * P.rt.C + rch + h * 64) * 2);
+      const unsigned lane_off = lstr + (unsigned)((pz ^ ((l16 & 1) << 2)) << 4);      // (bit 3 of the LDS row = l16 & 1)
+      const unsigned vo = (rowok && x0 + lx < P.W) ? lane_off : OOB;
+      char* dst = smem + buf * C::BUF + h * C::R_HALF + l16 * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+    };
+    // pieces 0 .. NT-1 = the dY tile, then the X patch; the late waves take the first NT - 4 NE, the early waves the rest
+    if (late_wave) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int li = wave * 8 + j;                            // instruction of the dY tile: LDS rows li*8 .. +7
-        const int h = li / C::R_INSTR, l16 = li % C::R_INSTR;
-        const int ty = l16 >> 2, c0 = (l16 & 3) * 8;            // tile row, first of the 8 columns (0..31)
-        const int img = PAIRED ? (c0 >> 4) : 0;
-        const int y = ty0 + ty, x0 = tx0 + (PAIRED ? (c0 & 15) : c0);
-        const bool rowok = y < P.H && img < nimg;
-        const unsigned so = (unsigned)img * r_img + (unsigned)(((y * P.rt.W + x0) * P.rt.C + rch + h * 64) * 2);
-        const unsigned lane_off = (j & 1) ? lane_off1 : lane_off0;        // (bit 3 of the LDS row = l16 & 1 = j & 1)
-        const unsigned vo = (rowok && x0 + lx < P.W) ? lane_off : OOB;
-        char* dst = smem + buf * C::BUF + h * C::R_HALF + l16 * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+      for (int j = 0; j < NLATE; ++j) {
+        const int idx = wave * NLATE + j;
+        if (idx >= NT - 4 * NE) break;
+        if (idx < NRH * C::R_INSTR) y_piece(idx);
+        else x_piece(idx - NRH * C::R_INSTR);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        const int i2 = (wave - NWR) * NX + j;
-        if (i2 >= NCH * C::C_INSTR) break;
-        const int h = NCH == 1 ? 0 : i2 / C::C_INSTR, li = NCH == 1 ? i2 : i2 % C::C_INSTR;
-        // (scalar selects: indexing CS[] with the run-time h would put the view into scratch memory)
-        const bool h1 = NCH > 1 && h == 1;
-        WView S;
-        S.p = h1 ? CS[NCH - 1].p : CS[0].p;  S.C = h1 ? CS[NCH - 1].C : CS[0].C;  S.H = h1 ? CS[NCH - 1].H : CS[0].H;
-        S.W = h1 ? CS[NCH - 1].W : CS[0].W;  S.oy = h1 ? CS[NCH - 1].oy : CS[0].oy;  S.ox = h1 ? CS[NCH - 1].ox : CS[0].ox;
-        const unsigned cimg = h1 ? c_img[NCH - 1] : c_img[0];
-        const int cchh = h1 ? cch[NCH - 1] : cch[0];
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(S.p + (size_t)n0 * cimg), (short)0, (int)(cimg * nimg), 0x00020000);
-        const int img = PAIRED ? li / (6 * C::IPR) : 0, lr = PAIRED ? li % (6 * C::IPR) : li;
-        const int prow = lr / C::IPR, pc0 = (lr % C::IPR) * 8;  // patch row, first of the 8 patch columns
-        const int row0 = img * C::IMGROWS + prow * C::PW + pc0; // first LDS row of the piece
-        const int y = ty0 + prow - 1 - S.oy, x0 = tx0 + pc0 - 1 - S.ox;
-        const bool rowok = y >= 0 && y < S.H && img < nimg;
-        // scalar part: the image row (never negative once rowok); the column (x0 may be -1) stays in the lane part
-        const unsigned so = (unsigned)img * cimg + (unsigned)((y * S.W * S.C + cchh) * 2);
-        const unsigned lane_off = (unsigned)(x0 + lx) * (unsigned)(S.C * 2) + (unsigned)((pz ^ (((row0 >> 3) & 1) << 2)) << 4);
-        const bool colok = (unsigned)(x0 + lx) < (unsigned)S.W && pc0 + lx < (PAIRED ? 18 : 34);
-        const unsigned vo = (rowok && colok) ? lane_off : OOB;
-        char* dst = smem + buf * C::BUF + NRH * C::R_HALF + h * C::C_HALF + row0 * 128;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void*)dst, 16, vo, rowok ? so : 0u, 0, 0);
+      for (int j = 0; j < NE; ++j) {
+        const int idx = NT - 4 * NE + (wave - 4) * NE + j;
+        if (idx < NRH * C::R_INSTR) y_piece(idx);
+        else x_piece(idx - NRH * C::R_INSTR);
       }
     }
   };
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     // always has MFMAs to issue (stamps: the earlier the dY waves issued, the more the two bursts overlapped).
     const bool more = tile + 1 < t_end;
 #ifndef W16_NO_DMA
-    if (more && !r_wave) { dma(buf ^ 1); WG_STAMP(2) }
+    if (more && !late_wave) { dma(buf ^ 1); WG_STAMP(2) }
 #endif
     const char* sb = smem;                                      // (a_off / b_off carry the buffer's offset)
     auto ldA = [&](int ty, int cb) {
@@ -692,19 +707,41 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
       return tr_frag2(sb, b_off[par][sx][0][nb] + prow * (C::PW * 128), b_off[par][sx][1][nb] + prow * (C::PW * 128));
     };
     bf16x8 fa[4][2], fb[3][2];                                  // dY rows: ring of 4 (rows p, p-1, p-2 live, p+1 in flight)
+    // A tile = 18 slots (patch row p, column shift sx) of 4 n_r(p) MFMAs, n_r = 1 2 3 3 2 1.  Every fragment is requested
+    // two or three slots before its first use, into registers retired by then: slot (p, 0) fetches the X fragments of
+    // (p, 2) and dY row p + 1, slot (p, 1) those of (p + 1, 0), slot (p, 2) those of (p + 1, 1).  Within a slot the
+    // ds_reads are INTERLEAVED one per MFMA (sched_group_barrier): a ds_read between two MFMAs is nearly free, a burst
+    // of eight after a group stalls the matrix pipe of a wave that is alone on its SIMD while its partner issues DMAs
+    // (hipcc left alone sinks the reads to their first use and waits there: half the MFMA rate).
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) fa[0][cb] = ldA(0, cb);
 #pragma unroll
-    for (int sx = 0; sx < 3; ++sx)
+    for (int nb = 0; nb < 2; ++nb) fb[0][nb] = ldB(0, 0, nb);
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) fb[sx][nb] = ldB(0, sx, nb);
+    for (int nb = 0; nb < 2; ++nb) fb[1][nb] = ldB(0, 1, nb);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx) {
-        // oldest dY row first: the most recently fetched one (r = 0) is used last
+        int nld = 0;
+        if (sx == 0) {
 #pragma unroll
-        for (int r = 2; r >= 0; --r) {
+          for (int nb = 0; nb < 2; ++nb) fb[2][nb] = ldB(p, 2, nb);
+          nld += 4;
+          if (p + 1 < 4) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) fa[(p + 1) & 3][cb] = ldA(p + 1, cb);
+            nld += 4;
+          }
+        } else if (p + 1 < 6) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) fb[sx - 1][nb] = ldB(p + 1, sx - 1, nb);
+          nld += 4;
+        }
+        int nmf = 0;
+#pragma unroll
+        for (int r = 2; r >= 0; --r) {                          // oldest dY row first
           const int ty = p - r;
           if (ty < 0 || ty > 3) continue;
 #pragma unroll
@@ -713,24 +750,19 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
             for (int nb = 0; nb < 2; ++nb)
               acc[r * 3 + sx][cb][nb] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ty & 3][cb], fb[sx][nb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
+          nmf += 4;
         }
-        // the X fragments of the NEXT patch row replace the ones just retired, >= 8 MFMAs before their first use.  The
-        // sched_barriers pin that distance: left alone hipcc sinks every ds_read to just above its first MFMA and
-        // waits for it there (lgkmcnt(0..2) every two MFMAs: a wave alone on its SIMD ran at half the MFMA rate)
-        __builtin_amdgcn_sched_barrier(0);
-        if (p + 1 < 6) {
+        // pipeline of the slot: MFMA, ds_read, MFMA, ds_read, ... then whatever is left of either
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) fb[sx][nb] = ldB(p + 1, sx, nb);
-        }
-        if (sx == 0 && p + 1 < 4) {                             // dY row p+1 into the ring slot of the retired row p-3
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) fa[(p + 1) & 3][cb] = ldA(p + 1, cb);
+        for (int i = 0; i < 12; ++i) {
+          if (i < nmf) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < nld) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #ifndef W16_NO_DMA
-    if (more && r_wave) { WG_STAMP(3) dma(buf ^ 1); WG_STAMP(2) }
+    if (more && late_wave) { WG_STAMP(3) dma(buf ^ 1); WG_STAMP(2) }
 #endif
     // the fragment addresses move to the other buffer IN PLACE (a second set of registers does not fit beside 200
     // accumulator / fragment registers)
