@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
 //    n+1), so the X fragment of (patch row p, column shift s) still serves the three (tile row, tap row) pairs with
 //    ty + r = p; the loop walks PATCH rows: per row 6 X fragments + 2 dY fragments (a 4-slot ring of dY rows), 12..36
 //    MFMAs; 36 independent accumulator chains (144 VGPRs) as before;
-//  * LDS rows are the natural 128 B (64 channels of one pixel); a patch row is padded to PW = 48 / 40 / 24 LDS rows so
+//  * LDS rows are the natural 128 B (64 channels of one pixel); a patch row is padded to PW = 48 / 40 / 32 LDS rows so
 //    that the 16-byte-piece XOR swizzle -- bits 1 and 3 of the LDS row index select one of four 32-byte bank groups, on
 //    the DMA's per-lane SOURCE address and on the transposed reads -- leaves the 8 pixel rows x 32 B of a
 //    ds_read_b64_tr_b16 half-wave in 8 different bank groups for every column shift (SQ_LDS_BANK_CONFLICT = 0), and
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams P) 
 // only up to fp32 summation order (K is walked in a different order).
 template <int NRH, int NCH, bool PAIRED>
 struct W16 {
-  static constexpr int PW = PAIRED ? 24 : (NCH == 1 ? 48 : 40); // LDS rows per patch row (18 / 34 of them used)
+  static constexpr int PW = PAIRED ? 32 : (NCH == 1 ? 48 : 40); // LDS rows per patch row (18 / 34 of them used)
   static constexpr bool PX = ((PW / 8) & 1) != 0;               // bit 3 of the LDS row flips with the patch row
   static constexpr int IMGROWS = 6 * PW;                        // LDS rows of one image's patch
   static constexpr int XROWS = (PAIRED ? 2 : 1) * IMGROWS;
@@ -500,7 +500,7 @@ struct W16 {
   static constexpr int IPR = PAIRED ? 3 : 5;                    // DMA pieces (8 LDS rows) per patch row that hold data
   static constexpr int R_INSTR = 16, C_INSTR = (PAIRED ? 2 : 1) * 6 * IPR;   // one-KiB DMA instructions per half
   static constexpr int BUF = NRH * R_HALF + NCH * C_HALF;
-  static constexpr int LDS = 2 * BUF + 1024;
+  static constexpr int LDS = 2 * BUF;                           // (paired: exactly the CU's 160 KiB)
   static constexpr int WR = 2 * NRH, WC = 2 * NCH;              // waves along gradient rows / columns (32 channels each)
   static_assert(WR * WC == 8, "eight waves");
   static_assert(LDS <= 160 * 1024, "LDS");
@@ -748,8 +748,8 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
           for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-              acc[r * 3 + sx][cb][nb] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ty & 3][cb], fb[sx][nb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
+              acc[r * 3 + sx][cb][nb] =     // D[X channel][dY channel]: a lane's 4 registers = 4 consecutive X channels
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[sx][nb], fa[ty & 3][cb], acc[r * 3 + sx][cb][nb], 0, 0, 0);
           nmf += 4;
         }
         // pipeline of the slot: MFMA, ds_read, MFMA, ds_read, ... then whatever is left of either
@@ -785,7 +785,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
   WG_STAMP(3)
   const unsigned long long wg_e0 = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- partial slab.  D of 16x16x32: column (X channel) = lane & 15, rows (dY channels) = (lane >> 4) * 4 + reg
+  // ---- partial slab [tap][dY channel][X channel].  The MFMAs ran with A = X, B = dY: D rows (lane >> 4) * 4 + reg = 4
+  // CONSECUTIVE X channels, column lane & 15 = the dY channel -> one 16-byte store per accumulator (36 per lane; with the
+  // operands the other way round it took 144 four-byte stores, and the store tail is issue-bound)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     float* o = P.partial + ((size_t)(sp * 9 + tap) * P.Crow) * P.Ccol;
@@ -793,12 +795,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const int col = ctile * 64 * NCH + wc * 32 + nb * 16 + i16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rch + wr * 32 + cb * 16 + g * 4 + r;
-          o[(size_t)row * P.Ccol + col] = acc[tap][cb][nb][r];
-        }
+        const int row = rch + wr * 32 + cb * 16 + i16;
+        const int col = ctile * 64 * NCH + wc * 32 + nb * 16 + g * 4;
+        *reinterpret_cast<f32x4*>(o + (size_t)row * P.Ccol + col) = acc[tap][cb][nb];
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -919,7 +918,10 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
     ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)",
                    alg_bytes);
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-      const int v16 = (impl == 0 || impl == '3') ? wgrad16_variant(P.W, P.Crow, P.Ccol) : 0;
+      // wgrad16_kernel: default for the forms it wins on (A/B per shape, profiles/r03_wgrad16.txt); UNET_WGRAD_IMPL=3
+      // forces it wherever it applies, 1 / 2 select the 32x32x16 kernel
+      int v16 = (impl == 0 || impl == '3') ? wgrad16_variant(P.W, P.Crow, P.Ccol) : 0;
+      if (impl == 0 && v16 == 3) v16 = 0;
       if (v16) {
         const Plan p16 = make_plan16(P.N, P.H, P.W, P.Crow, P.Ccol);
         P.tilesX = p16.tilesX; P.tilesY = p16.tilesY; P.nR = p16.nR; P.nC = p16.nC;
