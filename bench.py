@@ -125,9 +125,12 @@ def main():
     local = local % torch.cuda.device_count()            # (rehearsals may stack ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend, reserved = None, 0
     if world > 1:
         import torch.distributed as dist
+        from tiaozhanbei_unet_amd.ddp import configure_overlap
         backend = os.environ.get("UNET_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        reserved = configure_overlap()                          # RCCL channel cap + CU budget of the persistent kernels
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -263,6 +266,12 @@ def main():
         import torch.distributed as dist
         dist.barrier()
 
+    dist_seen = (None, 1)
+    if world > 1:
+        import torch.distributed as dist
+        dist_seen = (dist.get_backend(), dist.get_world_size())
+    from tiaozhanbei_unet_amd import _lib as _L
+    cu_budget = int(_L.lib().unet_get_cu_budget())
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
@@ -284,7 +293,10 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "accumulate": "fp32", "master_params": "fp32"},
+                       "accumulate": "fp32", "master_params": "fp32",
+                       # what torch.distributed actually saw (a SCALE record shows RCCL had N ranks) and the CU split
+                       "dist_backend": dist_seen[0], "dist_world": dist_seen[1],
+                       "reserved_cus": reserved, "cu_budget": cu_budget},
             "blocks": len(block_s),
             "ms_per_step_blocks": [round(1e3 * b / args.steps, 3) for b in block_s],
             "ms_per_step_p10": round(1e3 * pct(0.1) / args.steps, 3),

@@ -59,6 +59,16 @@ const char* unet_last_error(void);
  * them (same-process A/B tools such as tools/bench_layer.py --ab). */
 int32_t unet_tuning_reload(void);
 
+/* Data parallelism (no reference counterpart): CUs the persistent one-block-per-CU kernels leave free for
+ * the RCCL all-reduce kernels that overlap the backward pass.  The statically partitioned conv / weight-gradient /
+ * transposed-conv launchers size their grids by unet_get_cu_budget() = (multiprocessor count - reserved) rounded down
+ * to a multiple of 8 XCDs.  Default 0 (or UNET_RESERVED_CUS); ddp.py sets it when the world size is > 1. */
+int32_t unet_set_reserved_cus(int32_t n);
+int32_t unet_get_cu_budget(void);
+/* Diagnostic (tools/cu_share_probe.py): `blocks` workgroups holding `lds_bytes` of LDS spin for `microseconds` on `stream`
+ * -- a stand-in for resident collective kernels, to measure what CU sharing costs the persistent kernels. */
+int32_t unet_debug_spin(int32_t blocks, int32_t lds_bytes, int32_t microseconds, void* stream);
+
 /* ---- per-kernel-class timing (used by bench.py for the roofline object) -------------- */
 enum unet_kclass {
   UNET_K_CONV_FWD = 0, UNET_K_CONV_DGRAD, UNET_K_CONV_WGRAD, UNET_K_CONVT_FWD, UNET_K_CONVT_DGRAD,

@@ -115,3 +115,75 @@ def test_fused_adam_resumes_from_torch_checkpoint(decoupled, tmp_path):
     got3.step()
     for q, r in zip(net_got.parameters(), net3.parameters()):
         assert torch.equal(q, r)
+
+
+def test_reserved_cus_shrink_the_persistent_launches_and_keep_results():
+    """unet_set_reserved_cus (data parallelism leaves CUs to RCCL): the statically partitioned launchers are sized by
+    the CU budget; results do not depend on it beyond fp32 summation order (split-K slabs / statistics partials are
+    cut differently), and the conv outputs themselves are bit-identical."""
+    import ctypes as C
+    from tiaozhanbei_unet_amd import _lib as L, ops
+    lib = L.lib()
+    full = lib.unet_get_cu_budget()
+    assert full >= 8 and full % 8 == 0
+    try:
+        L.check(lib.unet_set_reserved_cus(20), "reserve")
+        assert lib.unet_get_cu_budget() == (full - 20) // 8 * 8
+        outs = {}
+        for reserved in (0, 20):
+            L.check(lib.unet_set_reserved_cus(reserved), "reserve")
+            torch.manual_seed(0)
+            import tiaozhanbei_unet_amd as P
+            m = P.AnomalyUNet(3, precision="bf16").to(DEV).train()
+            x = W.make_input("rcu:x", (4, 3, 128, 128)).to(DEV)
+            mk = W.make_input("rcu:m", (4, 1, 128, 128), kind="bernoulli").to(DEV)
+            r, a = m(x)
+            P.CombinedLoss()(r, a, x, mk)["total_loss"].backward()
+            torch.cuda.synchronize()
+            outs[reserved] = (r.detach().clone(), a.detach().clone(),
+                              {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        assert torch.equal(outs[0][0], outs[20][0]) and torch.equal(outs[0][1], outs[20][1])
+        worst = max(l2rel(outs[20][2][k], outs[0][2][k]) for k in outs[0][2])
+        assert worst < 2e-3, worst          # only the summation order of split-K slabs / BatchNorm partials moves
+    finally:
+        L.check(lib.unet_set_reserved_cus(0), "reserve")
+
+
+def test_one_rank_rccl_group_runs_the_gradient_exchange(tmp_path):
+    """The `nccl` (= RCCL) branch of ddp.GradientExchange -- ReduceOp.AVG, device_id= -- executes at least once: a
+    1-rank process group on this card (a multi-GPU node is the driver's; with one rank the exchange hooks are idle, so
+    the collective is also issued by hand on a bucket).  Run in a child process: a process group is process-global."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+from tiaozhanbei_unet_amd.ddp import DataParallel, configure_overlap
+import tiaozhanbei_unet_amd as P
+from tiaozhanbei_unet_amd import _lib as L
+dev = torch.device("cuda:0")
+r = configure_overlap(8)
+assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and L.lib().unet_get_cu_budget() %% 8 == 0
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+torch.manual_seed(0)
+m = P.AnomalyUNet(3, precision="bf16").to(dev).train()
+net = DataParallel(m)
+assert net.exchange._avg, "RCCL averages in-kernel"
+x = torch.randn(2, 3, 64, 64, device=dev); mk = torch.zeros(2, 1, 64, 64, device=dev)
+rec, am = net(x)
+P.CombinedLoss()(rec, am, x, mk)["total_loss"].backward()
+net.finish_gradients()
+flat = net.exchange.buckets[0]
+ref = flat.clone()
+h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
+h.wait()
+torch.cuda.synchronize()
+assert torch.equal(flat, ref), "AVG over one rank is the identity"
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % (ROOT, str(29500 + os.getpid() % 2000))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])

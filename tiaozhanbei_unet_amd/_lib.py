@@ -36,6 +36,9 @@ SIGNATURES = {
     "unet_abi_version": (_i, []),
     "unet_last_error": (C.c_char_p, []),
     "unet_tuning_reload": (_i, []),
+    "unet_set_reserved_cus": (_i, [_i]),
+    "unet_get_cu_budget": (_i, []),
+    "unet_debug_spin": (_i, [_i, _i, _i, _p]),
     "unet_prof_enable": (_i, [_i]),
     "unet_prof_collect": (_i, [_p, _p, _p]),
     "unet_prof_kernel_stats": (_i, [_i, _p, _p, _p, _p]),

@@ -33,6 +33,11 @@ int32_t unet_check_launch(const char* what);
 // (same-process A/B tools).  Each field is the first character of the variable's value, 0 when unset.
 struct UnetTuning { char conv_impl, conv_var, fused_stats, convt_impl, wgrad_impl, ws_stats, dgrad_bn, pdma_pp, ws_st, ws_mfma, wgrad_xcd, conv_xcd; };
 const UnetTuning& unet_tuning();
+// CUs the persistent (one-block-per-CU, statically partitioned) kernels may count on: the device's multiprocessor count
+// minus unet_set_reserved_cus() (a data-parallel run leaves a few CUs to the RCCL all-reduce kernels that overlap the
+// backward pass -- with all 256 claimed, a conv launch would wait for the CUs a collective holds and a static partition
+// then takes up to twice as long), rounded down to a multiple of 8 (XCDs), at least 8
+int unet_cu_budget();
 // opt a kernel in to `bytes` of dynamic LDS -- once per (device, kernel), cheap afterwards
 void unet_set_max_lds(const void* kernel, int bytes);
 

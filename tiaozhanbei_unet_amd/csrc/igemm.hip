@@ -1519,7 +1519,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
     UNET_REQUIRE(!bnbwd, UNET_ERR_UNSUPPORTED, "conv3_pdma: partial-sum buffer of %lld bytes", stat_bytes);
     P.stats = nullptr;
   }
-  const int blocks = (int)std::min<long long>(256, cdiv64(work, 8) * 8);   // one per CU, a multiple of 8 (XCDs)
+  const int blocks = (int)std::min<long long>(unet_cu_budget(), cdiv64(work, 8) * 8);   // one per (non-reserved) CU, a multiple of 8 (XCDs)
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   const long long n_tiles = (long long)P.N * P.tilesY * P.tilesX;
   P.zdiv = (P.stats && n_tiles % blocks == 0) ? 1 : 0;       // block-mode statistics: every block visits every channel tile
@@ -2410,7 +2410,7 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
     P.tilesY = cdiv(P.H, 16);
     const long long tiles16 = (long long)P.N * P.tilesY * P.tilesX;
     const int nCg16 = P.Cout / CfgWS16::ROWS;
-    int tpb16 = (int)cdiv64(tiles16 * nCg16, 256);
+    int tpb16 = (int)cdiv64(tiles16 * nCg16, unet_cu_budget());
     if (tpb16 < 2) tpb16 = 2;
     const long long ranges = cdiv64(cdiv64(tiles16, tpb16), 8) * 8;
     if (mode == 0) P.stats = nullptr;
@@ -2434,7 +2434,7 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   P.tilesY = cdiv(P.H, C::WTH);
   const long long tiles = (long long)P.N * P.tilesY * P.tilesX;
   const int nCg = P.Cout / C::ROWS;
-  int tpb = (int)cdiv64(tiles * nCg, 256);        // one resident block per CU, one round
+  int tpb = (int)cdiv64(tiles * nCg, unet_cu_budget());        // one resident block per CU, one round
   if (tpb < 2) tpb = 2;
   const long long ranges8 = cdiv64(cdiv64(tiles, tpb), 8) * 8;      // tile ranges, padded to a multiple of 8 (XCDs)
   const long long blocks = ranges8 * nCg;
@@ -2647,7 +2647,7 @@ int32_t launch_convt_ws(ConvTParams P, hipStream_t s) {
   const long long total_px = (long long)P.N * P.H * P.W;
   P.tiles = (int)cdiv64(total_px, C::TP);
   const int nCg = 4 * P.Cout / 256;
-  int tpb = (int)cdiv64((long long)P.tiles * nCg, 256);
+  int tpb = (int)cdiv64((long long)P.tiles * nCg, unet_cu_budget());
   if (tpb < 2) tpb = 2;
   P.tiles_per_block = tpb;
   const long long ranges8 = cdiv64(cdiv64(P.tiles, tpb), 8) * 8;
@@ -2903,7 +2903,7 @@ int32_t launch_convt_dgrad_ws(ConvTParams P, hipStream_t s, int* n_parts = nullp
   unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
   const long long total_px = (long long)P.N * P.H * P.W;
   P.tiles = (int)cdiv64(total_px, C::TP);
-  int tpb = (int)cdiv64(P.tiles, 256);
+  int tpb = (int)cdiv64(P.tiles, std::min(256, unet_cu_budget()));     // (partial buffer: 256 parts)
   if (tpb < 2) tpb = 2;
   P.tiles_per_block = tpb;
   const long long blocks = cdiv64(P.tiles, tpb);

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -62,6 +63,39 @@ extern "C" int32_t unet_tuning_reload(void) {
   read_tuning();
   return UNET_OK;
 }
+
+namespace {
+std::atomic<int> g_reserved_cus{-1};             // -1: not set -> UNET_RESERVED_CUS (default 0)
+int g_dev_cus[64] = {0};
+}  // namespace
+
+int unet_cu_budget() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int cus = g_dev_cus[dev];
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    g_dev_cus[dev] = cus;
+  }
+  int r = g_reserved_cus.load();
+  if (r < 0) {
+    const char* v = getenv("UNET_RESERVED_CUS");
+    r = v ? atoi(v) : 0;
+    if (r < 0) r = 0;
+    g_reserved_cus.store(r);
+  }
+  int b = (cus - r) / 8 * 8;
+  return b < 8 ? 8 : b;
+}
+
+extern "C" int32_t unet_set_reserved_cus(int32_t n) {
+  UNET_REQUIRE(n >= 0 && n < 1024, UNET_ERR_BAD_ARG, "unet_set_reserved_cus: %d", n);
+  g_reserved_cus.store(n);
+  return UNET_OK;
+}
+
+extern "C" int32_t unet_get_cu_budget(void) { return unet_cu_budget(); }
 
 void unet_set_max_lds(const void* kernel, int bytes) {
   int dev = 0;
@@ -155,4 +189,27 @@ extern "C" int32_t unet_prof_kernel_bytes(int32_t index, double* bytes) {
                g_kstats.size());
   *bytes = g_kstats[index].bytes;
   return UNET_OK;
+}
+
+// ------------------------------------------------------------------------------ diagnostic: CU occupier
+// tools/cu_share_probe.py: `blocks` workgroups that each hold `lds_bytes` of LDS and spin for `microseconds` -- a
+// stand-in for the RCCL all-reduce kernels a data-parallel run keeps resident on a few CUs during the backward pass
+// (one block per channel, tens of KiB of LDS each).  A CU that hosts one cannot take a persistent conv block (125-160 KiB
+// of LDS), so a launch sized for every CU runs a second round; unet_set_reserved_cus() sizes the launches for the rest.
+namespace {
+__global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, int lds_words) {
+  extern __shared__ unsigned spin_lds[];
+  if (lds_words > 0) spin_lds[threadIdx.x % lds_words] = threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (lds_words > 0 && spin_lds[0] == 0xFFFFFFFFu) __builtin_trap();       // (keeps the LDS allocation alive)
+}
+}  // namespace
+
+extern "C" int32_t unet_debug_spin(int32_t blocks, int32_t lds_bytes, int32_t microseconds, void* stream) {
+  UNET_REQUIRE(blocks > 0 && blocks <= 1024 && lds_bytes >= 0 && lds_bytes <= 64 * 1024 && microseconds > 0 &&
+                   microseconds <= 2000000, UNET_ERR_BAD_ARG, "unet_debug_spin: bad arguments");
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                     (unsigned long long)microseconds * 100ull, lds_bytes / 4);
+  return unet_check_launch("spin_kernel");
 }

@@ -584,6 +584,8 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
   constexpr int NT = NRH * C::R_INSTR + NCH * C::C_INSTR;      // pieces per tile: 62 (128x64 wide), 68 (paired), 76 (64x128)
   constexpr int NE = W16_NE;
   constexpr int NLATE = (NT - 4 * NE + 3) / 4;
+  // (measured: the waves that compute FIRST must be the ones that win the SIMD's issue arbitration -- the older waves
+  //  0-3; the roles swapped, or the early waves raised with s_setprio, cost 8-13 %)
   const bool late_wave = wave < 4;
   const unsigned r_img = (unsigned)P.rt.H * P.rt.W * P.rt.C * 2u;
   unsigned c_img[NCH];
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     if (late_wave) {
 #pragma unroll
       for (int j = 0; j < NLATE; ++j) {
-        const int idx = wave * NLATE + j;
+        const int idx = (wave & 3) * NLATE + j;
         if (idx >= NT - 4 * NE) break;
         if (idx < NRH * C::R_INSTR) y_piece(idx);
         else x_piece(idx - NRH * C::R_INSTR);
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(const WgradParams P) {
     } else {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
-        const int idx = NT - 4 * NE + (wave - 4) * NE + j;
+        const int idx = NT - 4 * NE + (wave & 3) * NE + j;
         if (idx < NRH * C::R_INSTR) y_piece(idx);
         else x_piece(idx - NRH * C::R_INSTR);
       }
@@ -854,7 +856,7 @@ Plan make_plan(int n, int h, int w, int crow, int ccol) {
   p.nR = crow / 64;
   p.nC = ccol / 64;
   const long long ntiles = (long long)n * p.tilesY * p.tilesX;
-  long long want = 512 / ((long long)p.nR * p.nC);
+  long long want = 2LL * unet_cu_budget() / ((long long)p.nR * p.nC);      // two 256-thread blocks per CU
   if (want < 1) want = 1;
   if (want > ntiles) want = ntiles;
   p.tilesPerSplit = (int)cdiv64(ntiles, want);
@@ -878,7 +880,7 @@ inline Plan make_plan16(int n, int h, int w, int crow, int ccol) {
   p.nR = v == 3 ? crow / 64 : crow / 128;
   p.nC = v == 3 ? ccol / 128 : ccol / 64;
   const long long ntiles = (long long)(v == 2 ? (n + 1) / 2 : n) * p.tilesY * p.tilesX;
-  long long want = 256 / ((long long)p.nR * p.nC);
+  long long want = (long long)unet_cu_budget() / ((long long)p.nR * p.nC);   // one 512-thread block per CU
   if (want < 1) want = 1;
   if (want > ntiles) want = ntiles;
   p.tilesPerSplit = (int)cdiv64(ntiles, want);
@@ -915,13 +917,17 @@ int32_t run(WgradParams& P, const Plan& pl, float* out, int rows_out, int cols_o
     // algorithmic bytes: both activation tensors once + the fp32 gradient once (split-K slabs are overhead, not counted)
     const double alg_bytes = (double)P.N * P.H * P.W * ((double)P.Crow + P.Ccol * (TAPS == 9 ? 1.0 : 4.0)) * sizeof(T) +
                              4.0 * TAPS * rows_out * cols_out;
-    ProfScope prof(kclass, flops, s, (sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)",
-                   alg_bytes);
+    // wgrad16_kernel: default for the forms it wins on (A/B per shape, profiles/r03_wgrad16.txt); UNET_WGRAD_IMPL=3
+    // forces it wherever it applies, 1 / 2 select the 32x32x16 kernel
+    int v16 = 0;
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-      // wgrad16_kernel: default for the forms it wins on (A/B per shape, profiles/r03_wgrad16.txt); UNET_WGRAD_IMPL=3
-      // forces it wherever it applies, 1 / 2 select the 32x32x16 kernel
-      int v16 = (impl == 0 || impl == '3') ? wgrad16_variant(P.W, P.Crow, P.Ccol) : 0;
+      v16 = (impl == 0 || impl == '3') ? wgrad16_variant(P.W, P.Crow, P.Ccol) : 0;
       if (impl == 0 && v16 == 3) v16 = 0;
+    }
+    ProfScope prof(kclass, flops, s,
+                   v16 ? "wgrad16_kernel (+ reduce)"
+                       : ((sizeof(T) == 2 && TAPS == 9) ? "wgrad_dma_kernel (+ reduce)" : "wgrad_kernel (+ reduce)"), alg_bytes);
+    if constexpr (sizeof(T) == 2 && TAPS == 9) {
       if (v16) {
         const Plan p16 = make_plan16(P.N, P.H, P.W, P.Crow, P.Ccol);
         P.tilesX = p16.tilesX; P.tilesY = p16.tilesY; P.nR = p16.nR; P.nC = p16.nC;
@@ -1218,7 +1224,8 @@ int32_t launch_convt_wgrad_ws(const void* x, const void* dy, int n, int h, int w
   const long long px = (long long)n * h * w;
   CtwParams P{(const char*)x, (const char*)dy, (float*)workspace, n, h, w, (int)(px / C::TP), 0};
   const int yb = C::RB * C::CB;
-  int nsplit = 512 / yb;
+  int nsplit = 2 * unet_cu_budget() / yb;
+  if (nsplit < 1) nsplit = 1;
   if (nsplit > P.tiles) nsplit = P.tiles;
   P.tiles_per_split = (P.tiles + nsplit - 1) / nsplit;
   nsplit = (P.tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1247,7 +1254,8 @@ inline bool convt_wgrad_ws_ok(int dtype, int n, int h, int w, int c_in, int c_ou
 inline size_t convt_wgrad_ws_bytes(int n, int h, int w, int c_in) {
   const long long tiles = (long long)n * h * w / 32;
   const int yb = (c_in / 128) * (c_in / 128);
-  long long nsplit = 512 / yb;
+  long long nsplit = 2 * unet_cu_budget() / yb;
+  if (nsplit < 1) nsplit = 1;
   if (nsplit > tiles) nsplit = tiles;
   return (size_t)nsplit * (c_in + 1) * (2 * c_in) * sizeof(float);
 }

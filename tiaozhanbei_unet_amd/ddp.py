@@ -29,6 +29,30 @@ import torch.distributed as dist
 from . import ops
 
 
+DEFAULT_RESERVED_CUS = 16
+
+
+def configure_overlap(reserved_cus: int = None) -> int:
+    """Call BEFORE ``init_process_group`` in a multi-GPU run.  The persistent conv / weight-gradient kernels partition
+    their work statically over one block per CU with 125-160 KiB of LDS each; an RCCL all-reduce kernel resident on a CU
+    during the backward pass (one block per channel) leaves no room for such a block, and a launch sized for all 256 CUs
+    would then run a second round for the displaced blocks.  So: RCCL is capped at ``reserved_cus`` channels
+    (``NCCL_MAX_NCHANNELS`` / ``NCCL_MIN_NCHANNELS``, unless the user set them) and the launchers are sized for the
+    remaining CUs (``unet_set_reserved_cus``).  ``UNET_DDP_RESERVED_CUS`` overrides the default of 16 (a 16-channel ring
+    keeps the 7 xGMI links of a GPU busy; the one-GPU probe, tools/cu_share_probe.py, prices the trade)."""
+    import os
+    from . import _lib as L
+    if reserved_cus is None:
+        reserved_cus = int(os.environ.get("UNET_DDP_RESERVED_CUS", DEFAULT_RESERVED_CUS))
+    reserved_cus = max(0, int(reserved_cus))
+    if reserved_cus:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(reserved_cus))
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(reserved_cus, int(os.environ["NCCL_MAX_NCHANNELS"]))))
+    if torch.cuda.is_available():
+        L.check(L.lib().unet_set_reserved_cus(reserved_cus), "unet_set_reserved_cus")
+    return reserved_cus
+
+
 class GradientExchange:
     """Bucketed, overlapped gradient averaging for ``params`` (any device torch.distributed supports)."""
 

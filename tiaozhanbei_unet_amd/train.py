@@ -83,6 +83,8 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
+        from .ddp import configure_overlap
+        configure_overlap()                 # RCCL channel cap + CU budget of the persistent kernels, before the communicator exists
         torch.distributed.init_process_group("nccl", device_id=device)
     say = print if rank == 0 else (lambda *a, **k: None)
     say(f"Using device: {device}\nTraining category: {args.category}")
