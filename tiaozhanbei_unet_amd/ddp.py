@@ -29,17 +29,20 @@ import torch.distributed as dist
 from . import ops
 
 
-DEFAULT_RESERVED_CUS = 16
+DEFAULT_RESERVED_CUS = 32
 
 
 def configure_overlap(reserved_cus: int = None) -> int:
     """Call BEFORE ``init_process_group`` in a multi-GPU run.  The persistent conv / weight-gradient kernels partition
-    their work statically over one block per CU with 125-160 KiB of LDS each; an RCCL all-reduce kernel resident on a CU
-    during the backward pass (one block per channel) leaves no room for such a block, and a launch sized for all 256 CUs
-    would then run a second round for the displaced blocks.  So: RCCL is capped at ``reserved_cus`` channels
-    (``NCCL_MAX_NCHANNELS`` / ``NCCL_MIN_NCHANNELS``, unless the user set them) and the launchers are sized for the
-    remaining CUs (``unet_set_reserved_cus``).  ``UNET_DDP_RESERVED_CUS`` overrides the default of 16 (a 16-channel ring
-    keeps the 7 xGMI links of a GPU busy; the one-GPU probe, tools/cu_share_probe.py, prices the trade)."""
+    their work statically over one block per CU with 125-160 KiB of LDS each; a collective kernel resident on a CU during
+    the backward pass (one block per RCCL channel, tens of KiB of LDS) leaves no room for such a block, and the displaced
+    blocks of a launch sized for all 256 CUs run as a second round.  So RCCL is capped at ``reserved_cus`` channels
+    (``NCCL_MAX_NCHANNELS``, unless the user set it) and the launchers are sized for the remaining CUs
+    (``unet_set_reserved_cus``).  Default 32 (``UNET_DDP_RESERVED_CUS``), from the one-GPU probe
+    (tools/cu_share_probe.py, profiles/r03_cu_share_probe.txt): workgroups are dealt round-robin to the 8 XCDs and, inside
+    an XCD, to its 4 shader engines of 8 CUs, so ONE occupied CU per engine already takes a full engine's worth of
+    blocks out of a launch: 8 .. 32 resident 48-KiB workgroups cost +21 % per step with the launchers at 256, 248 or 232
+    blocks and +8 % at 224 (7 blocks per engine); giving up the 32 CUs costs +5 % by itself."""
     import os
     from . import _lib as L
     if reserved_cus is None:
@@ -47,7 +50,6 @@ def configure_overlap(reserved_cus: int = None) -> int:
     reserved_cus = max(0, int(reserved_cus))
     if reserved_cus:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(reserved_cus))
-        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(reserved_cus, int(os.environ["NCCL_MAX_NCHANNELS"]))))
     if torch.cuda.is_available():
         L.check(L.lib().unet_set_reserved_cus(reserved_cus), "unet_set_reserved_cus")
     return reserved_cus

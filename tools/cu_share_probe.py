@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--fine", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.lib()
@@ -46,13 +47,13 @@ def main():
         loss.backward()
         opt.step()
 
-    def timed(spinners, reserved):
+    def timed(spinners, lds, reserved):
         L.check(lib.unet_set_reserved_cus(reserved), "reserve")
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         if spinners:           # resident for the whole timed region (2 s is far longer than it)
-            L.check(lib.unet_debug_spin(spinners, 48 * 1024, 2_000_000, C.c_void_p(side.cuda_stream)), "spin")
+            L.check(lib.unet_debug_spin(spinners, lds, 2_000_000, C.c_void_p(side.cuda_stream)), "spin")
             time.sleep(0.01)
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -63,10 +64,16 @@ def main():
         return round(dt, 3)
 
     rows = []
-    for k in (0, 4, 8, 16, 32):
-        row = {"spinning_blocks": k, "ms_per_step": {}}
-        for r in sorted({0, k, max(k, 8) if k else 0, 16 if k <= 16 else 32}):
-            row["ms_per_step"][f"reserved_{r}"] = timed(k, r)
+    # (spinning blocks, LDS each): 0-LDS spinners share a CU with a conv block -- they isolate the cost of a second
+    # active queue from the cost of displaced blocks
+    cases = ((0, 0), (1, 0), (8, 0), (8, 48 * 1024), (16, 48 * 1024), (32, 48 * 1024))
+    reserves = (0, 8, 16, 32)
+    if a.fine:          # where is the threshold?  (8 spinners; 16 / 48 KiB each)
+        cases, reserves = ((8, 16 * 1024), (8, 48 * 1024)), (0, 8, 16, 24, 32, 40, 64)
+    for k, lds in cases:
+        row = {"spinning_blocks": k, "lds_each": lds, "ms_per_step": {}}
+        for r in reserves:
+            row["ms_per_step"][f"reserved_{r}"] = timed(k, lds, r)
         rows.append(row)
         print(json.dumps(row), flush=True)
     L.check(lib.unet_set_reserved_cus(0), "reserve")
