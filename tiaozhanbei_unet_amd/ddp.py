@@ -29,7 +29,7 @@ import torch.distributed as dist
 from . import ops
 
 
-DEFAULT_RESERVED_CUS = 32
+DEFAULT_RESERVED_CUS = 0
 
 
 def configure_overlap(reserved_cus: int = None) -> int:
@@ -38,11 +38,14 @@ def configure_overlap(reserved_cus: int = None) -> int:
     the backward pass (one block per RCCL channel, tens of KiB of LDS) leaves no room for such a block, and the displaced
     blocks of a launch sized for all 256 CUs run as a second round.  So RCCL is capped at ``reserved_cus`` channels
     (``NCCL_MAX_NCHANNELS``, unless the user set it) and the launchers are sized for the remaining CUs
-    (``unet_set_reserved_cus``).  Default 32 (``UNET_DDP_RESERVED_CUS``), from the one-GPU probe
-    (tools/cu_share_probe.py, profiles/r03_cu_share_probe.txt): workgroups are dealt round-robin to the 8 XCDs and, inside
-    an XCD, to its 4 shader engines of 8 CUs, so ONE occupied CU per engine already takes a full engine's worth of
-    blocks out of a launch: 8 .. 32 resident 48-KiB workgroups cost +21 % per step with the launchers at 256, 248 or 232
-    blocks and +8 % at 224 (7 blocks per engine); giving up the 32 CUs costs +5 % by itself."""
+    (``unet_set_reserved_cus``).  The one-GPU probe (tools/cu_share_probe.py, profiles/r03_cu_share_probe.txt) prices the
+    trade: workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, to its 4 shader engines of 8 CUs, so ONE
+    occupied CU per engine already takes a full engine's worth of blocks out of a launch: 8 .. 32 resident 48-KiB
+    workgroups cost +21 % WHILE they are resident with the launchers at 256, 248 or 232 blocks and +8 % at 224 (7 blocks
+    per engine -> the only useful reservation is 32); giving up the 32 CUs costs +5 % of EVERY step.  The gradient
+    all-reduce of this model (172.9 MB) keeps RCCL kernels resident for an estimated 5-10 % of a step, where the
+    unreserved penalty (<= 21 % of that) stays below the reservation's 5 %: the default is therefore 0 (no reservation,
+    RCCL's own channel count); ``UNET_DDP_RESERVED_CUS=32`` switches the reservation on for an A/B on a multi-GPU node."""
     import os
     from . import _lib as L
     if reserved_cus is None:
