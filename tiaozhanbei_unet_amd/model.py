@@ -381,10 +381,21 @@ class AnomalyUNet(_HipBlock):
         with _BatchedCounters():
             return self._forward(x)
 
+    _warned_off = False
+
     def _forward(self, x):
         ops._require_cuda(x)
         _pack_cache(self)
         feats = _encoder(self, x)
+        if self.two_streams and torch.is_grad_enabled() and not AnomalyUNet._warned_off:
+            # The segmentation decoder's weight gradients are produced on the side stream, their AccumulateGrad nodes
+            # belong to the stream the parameters live on: autograd orders the two with an event wait -- exactly the
+            # dependency the optimiser step needs -- and warns about it once per process.  The wait is wanted; the
+            # warning is not.
+            setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if setter is not None:
+                setter(False)
+            AnomalyUNet._warned_off = True
         if not self.two_streams:
             return self._decode(feats, "recon"), self._decode(feats, "seg")
         main = torch.cuda.current_stream(x.device)
