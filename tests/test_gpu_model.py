@@ -226,7 +226,8 @@ def test_double_conv_at_benchmark_size_against_torch():
     with O.bf16_storage():
         yr = O.double_conv(work, "b", xr, True)
         yr.backward(g)
-    assert maxabs(y, yr) < 3e-2, maxabs(y, yr)
+    # (one bf16 ulp of the largest activations, ~5 sigma after BatchNorm, is 2^-5)
+    assert maxabs(y, yr) <= 1.2e-2 * max(1.0, float(yr.abs().max())), (maxabs(y, yr), float(yr.abs().max()))
     assert l2rel(xd.grad, xr.grad) < 3e-2, l2rel(xd.grad, xr.grad)
     for k in ("double_conv.0.weight", "double_conv.3.weight", "double_conv.1.weight", "double_conv.4.bias"):
         got = dict(dc.named_parameters())[k].grad
