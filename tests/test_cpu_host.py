@@ -94,7 +94,7 @@ def test_mvtec_reader_contract(tmp_path):
     from tiaozhanbei_unet_amd.dataset import get_available_categories, get_dataloaders, write_synthetic_mvtec
     root = write_synthetic_mvtec(str(tmp_path), "bottle", n_train=3, n_good=2, n_bad=2, size=40)
     assert get_available_categories(root) == ["bottle"]
-    train, test = get_dataloaders(root, "bottle", batch_size=2, image_size=32, num_workers=0)
+    train, test = get_dataloaders(root, "bottle", batch_size=2, image_size=32, num_workers=0, device_preprocess=False)
     b = next(iter(train))
     assert set(b) == {"image", "mask", "label", "anomaly_type", "image_path"}
     assert b["image"].shape == (2, 3, 32, 32) and b["mask"].shape == (2, 1, 32, 32)
@@ -104,6 +104,21 @@ def test_mvtec_reader_contract(tmp_path):
         labels += b["label"].tolist(); mx = max(mx, float(b["mask"].max()))
     assert sorted(labels) == [0, 0, 1, 1]
     assert 0 < mx <= 1.0 / 255.0 + 1e-9, "masks are {0,1} uint8 scaled by 1/255 (reference quirk)"
+    # device_preprocess form (what the GPU box uses): the same samples as uint8 HWC + flip flag; host normalisation of
+    # those bytes reproduces the float form exactly (the device does that arithmetic in unet_preprocess_u8)
+    import random
+    import numpy as np
+    from tiaozhanbei_unet_amd import dataset as D
+    for split, is_train in (("train", True), ("test", False)):
+        random.seed(5)
+        host = [D.MVTecDataset(root, "bottle", split, 32, is_train, device_preprocess=False)[i] for i in range(2)]
+        random.seed(5)
+        dev_ = [D.MVTecDataset(root, "bottle", split, 32, is_train, device_preprocess=True)[i] for i in range(2)]
+        for h, d in zip(host, dev_):
+            assert set(d) == {"image_u8", "flip", "mask", "label", "anomaly_type", "image_path"}
+            assert d["image_u8"].dtype == torch.uint8 and tuple(d["image_u8"].shape) == (32, 32, 3)
+            assert torch.equal(D._normalise(d["image_u8"].numpy(), bool(d["flip"])), h["image"])
+            assert torch.equal(d["mask"], h["mask"])
 
 
 def test_shard_sampler_gives_disjoint_equal_shards():

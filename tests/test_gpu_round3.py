@@ -187,3 +187,28 @@ print("RCCL_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+def test_mvtec_loader_preprocesses_on_the_device_bit_identically(tmp_path):
+    """the MVTec loaders built on a GPU box ship uint8 HWC images + flip flags; train_utils._batches turns
+    a batch into normalised fp32 NCHW with ONE unet_preprocess_u8 launch -- bit-identical to the host arithmetic of
+    src/dataset.py:134-146 (ToTensor, Normalize) on the same bytes, flips included."""
+    import random
+    from tiaozhanbei_unet_amd import dataset as D, train_utils as T
+    root = D.write_synthetic_mvtec(str(tmp_path), "bottle", n_train=6, n_good=2, n_bad=2, size=48)
+    tr_dev, te_dev = D.get_dataloaders(root, "bottle", batch_size=3, image_size=40, num_workers=0)       # default on a GPU box
+    assert tr_dev.dataset.device_preprocess and te_dev.dataset.device_preprocess
+    for split, is_train in (("train", True), ("test", False)):
+        host = D.MVTecDataset(root, "bottle", split, 40, is_train, device_preprocess=False)
+        dev_ = D.MVTecDataset(root, "bottle", split, 40, is_train, device_preprocess=True)
+        random.seed(11)
+        hb = [host[i] for i in range(len(host))]
+        random.seed(11)
+        loader = torch.utils.data.DataLoader(dev_, batch_size=len(dev_), shuffle=False, num_workers=0)
+        (batch, images, masks), = list(T._batches(loader, DEV))
+        assert images.shape == (len(host), 3, 40, 40) and images.dtype == torch.float32 and images.is_cuda
+        want = torch.stack([b["image"] for b in hb])
+        assert torch.equal(images.cpu(), want), float((images.cpu() - want).abs().max())
+        assert torch.equal(masks.cpu(), torch.stack([b["mask"] for b in hb]))
+        if is_train:
+            assert 0 < int(batch["flip"].sum()) < len(host), "seed 11 draws both flipped and unflipped samples"

@@ -3,8 +3,9 @@
 Mirrors /root/reference/src/dataset.py: directory layout and label rules (:38-89), the batch dict keys
 `image, mask, label, anomaly_type, image_path` (:121-127), resize + ImageNet normalisation (:134-146) and
 the reference's mask quirk -- masks are binarised to {0,1} uint8 and then scaled by 1/255 (:101-103,:149-152),
-so targets are {0, 1/255}.  torchvision is absent from this environment, so transforms are PIL + numpy
-(ColorJitter is not reproduced; flip and +-10 degree rotation are).  `write_synthetic_mvtec` creates a small
+so targets are {0, 1/255}.  torchvision is absent from this environment, so resize / rotation are PIL (ColorJitter is
+not reproduced; flip and +-10 degree rotation are); flip + ToTensor + Normalize run on the GPU when the loaders are
+built with ``device_preprocess`` (the default where a GPU is present): one unet_preprocess_u8 launch per batch.  `write_synthetic_mvtec` creates a small
 MVTec-layout tree of PNGs for CLI plumbing tests; `--synthetic` in train.py uses it.
 """
 from __future__ import annotations
@@ -22,14 +23,31 @@ MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
 STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
 
 
-def _image_tensor(img: Image.Image, size, train: bool) -> torch.Tensor:
+def _image_u8(img: Image.Image, size, train: bool):
+    """Host half of the image transform: resize (+ the train-time flip decision and +-10 degree rotation) -> uint8 HWC
+    and the flip flag.  Flip, ToTensor and Normalize happen in _normalise (host) or in ONE unet_preprocess_u8 launch per
+    batch (device, train_utils._batches): the workers then ship 1 byte per sample instead of 4."""
     img = img.resize((size[1], size[0]), Image.BILINEAR)
+    flip = False
     if train:
-        if random.random() < 0.5:
-            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        flip = random.random() < 0.5
+        if flip:                        # (the rotation of the reference follows the flip: rotate the flipped image,
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)      #  then flip back so that the deferred flip reproduces it)
         img = img.rotate(random.uniform(-10.0, 10.0), resample=Image.NEAREST)
-    a = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0
-    return torch.from_numpy((a - MEAN) / STD)
+        if flip:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8)), flip
+
+
+def _normalise(u8: np.ndarray, flip: bool) -> torch.Tensor:
+    if flip:
+        u8 = u8[:, ::-1]
+    a = u8.astype(np.float32).transpose(2, 0, 1) / 255.0
+    return torch.from_numpy(np.ascontiguousarray((a - MEAN) / STD))
+
+
+def _image_tensor(img: Image.Image, size, train: bool) -> torch.Tensor:
+    return _normalise(*_image_u8(img, size, train))
 
 
 def _mask_tensor(mask: Image.Image, size) -> torch.Tensor:
@@ -38,7 +56,11 @@ def _mask_tensor(mask: Image.Image, size) -> torch.Tensor:
 
 
 class MVTecDataset(Dataset):
-    def __init__(self, root_dir, category, split="train", image_size=256, is_train=True):
+    def __init__(self, root_dir, category, split="train", image_size=256, is_train=True, device_preprocess=False):
+        """``device_preprocess``: samples carry ``image_u8`` (uint8 HWC) + ``flip`` instead of the normalised ``image``;
+        ``train_utils._batches`` turns a batch of them into the same fp32 NCHW tensor with one unet_preprocess_u8
+        launch (bit-identical to the host arithmetic)."""
+        self.device_preprocess = bool(device_preprocess)
         self.size = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
         self.split, self.is_train = split, is_train
         self.image_paths, self.mask_paths, self.labels, self.anomaly_types = [], [], [], []
@@ -73,8 +95,14 @@ class MVTecDataset(Dataset):
         else:
             m = np.zeros((img.size[1], img.size[0]), dtype=np.uint8)
         train_aug = self.split == "train"
-        return {"image": _image_tensor(img, self.size, train_aug), "mask": _mask_tensor(Image.fromarray(m), self.size),
-                "label": self.labels[i], "anomaly_type": self.anomaly_types[i], "image_path": self.image_paths[i]}
+        u8, flip = _image_u8(img, self.size, train_aug)
+        out = {"mask": _mask_tensor(Image.fromarray(m), self.size), "label": self.labels[i],
+               "anomaly_type": self.anomaly_types[i], "image_path": self.image_paths[i]}
+        if self.device_preprocess:
+            out["image_u8"], out["flip"] = torch.from_numpy(u8), int(flip)
+        else:
+            out["image"] = _normalise(u8, flip)
+        return out
 
 
 class ShardSampler(torch.utils.data.Sampler):
@@ -111,11 +139,14 @@ class ShardSampler(torch.utils.data.Sampler):
         return self.per_rank
 
 
-def get_dataloaders(root_dir, category, batch_size=16, image_size=256, num_workers=4, rank=0, world=1, seed=0):
+def get_dataloaders(root_dir, category, batch_size=16, image_size=256, num_workers=4, rank=0, world=1, seed=0,
+                    device_preprocess=None):
     """(train_loader, test_loader) like the reference's (src/dataset.py:157-199).  With ``world > 1`` the train loader
     draws from this rank's ShardSampler shard (``loader.sampler.set_epoch(e)`` reshuffles); the test loader is whole."""
-    train = MVTecDataset(root_dir, category, "train", image_size, is_train=True)
-    test = MVTecDataset(root_dir, category, "test", image_size, is_train=False)
+    if device_preprocess is None:          # on the GPU box: flip + ToTensor + Normalize on the device
+        device_preprocess = torch.cuda.is_available()
+    train = MVTecDataset(root_dir, category, "train", image_size, is_train=True, device_preprocess=device_preprocess)
+    test = MVTecDataset(root_dir, category, "test", image_size, is_train=False, device_preprocess=device_preprocess)
     kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available())
     if world > 1:
         sampler = ShardSampler(len(train), rank, world, shuffle=True, seed=seed)

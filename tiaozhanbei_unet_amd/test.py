@@ -42,8 +42,8 @@ def test_model(model, test_loader, device, threshold=None):
     out = {k: [] for k in ("images", "reconstructions", "anomaly_maps", "masks_true", "labels", "anomaly_types",
                            "image_paths", "anomaly_scores")}
     with torch.no_grad():
-        for batch in test_loader:
-            images = batch["image"].to(device)
+        from .train_utils import _batches
+        for batch, images, _ in _batches(test_loader, device):     # (uint8 batches are normalised on the device)
             if isinstance(model, AnomalyUNet):
                 recon, amap = model(images)
             else:

@@ -61,8 +61,15 @@ class CombinedLoss(nn.Module):
 
 
 def _batches(loader, device):
+    """(batch dict, images, masks) on the device.  Loaders built with ``device_preprocess`` ship uint8 HWC images and
+    flip flags: flip + ToTensor + Normalize (src/dataset.py:134-146) are one unet_preprocess_u8 launch per batch."""
     for batch in loader:
-        yield batch, batch["image"].to(device, non_blocking=True), batch["mask"].to(device, non_blocking=True)
+        if "image_u8" in batch:
+            images = ops.preprocess_u8(batch["image_u8"].to(device, non_blocking=True), batch["flip"])
+            batch["image"] = images
+        else:
+            images = batch["image"].to(device, non_blocking=True)
+        yield batch, images, batch["mask"].to(device, non_blocking=True)
 
 
 def train_epoch(model, train_loader, criterion, optimizer, device, epoch, step_hook=None):
