@@ -54,6 +54,7 @@ struct IgemmParams {
   const float* bn_scale;
   const float* bn_shift;
   const float* bn_mean;
+  int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off)
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -2067,6 +2068,9 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
   }
   float stat_tot = 0.f;
   const int ch0 = cg * C::ROWS + wco * 32;          // first output channel of this wave
+  // (the gradient fan-in form keeps every wave's DMAs in front: its old-value loads are builtin loads, whose
+  //  compiler-placed wait would drain DMAs issued behind them)
+  const bool late = !ACC && P.ws_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
 
   // ---- this wave's weights -> registers: A fragment (tile ct, tap, ks) = W[ch0 + 16ct + l15][tap][32ks + 8kb .. +7]
   bf16x8 wreg[2][18];
@@ -2220,7 +2224,14 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       for (int pt = 0; pt < 4; ++pt)             // inline asm + hand-counted wait (hipcc does not count LDS-DMAs)
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(yv[pt]) : "v"(ovo[pt][0]), "s"(yrs) : "memory");
     }
-    if (ALWAYS || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
+    // The patch DMAs of tile k + 2.  A wave inside its burst of six one-KiB issues feeds no MFMAs, and with all eight
+    // waves bursting behind the barrier the matrix pipe idles for the whole burst (r02 stamps: the burst costs as much
+    // as the tile's 72 MFMAs).  The two waves of a SIMD (w, w + 4) therefore issue at opposite ends of the tile: waves
+    // 4-7 here, waves 0-3 -- the older ones, which win the SIMD's issue arbitration and so should compute first -- behind
+    // their MFMAs, still in front of the tile's stores (the vmcnt bookkeeping above counts the same operations either way).
+    if (!late) {
+      if (ALWAYS || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
+    }
     u32x4 oldv[ACC ? 4 : 1];
     if constexpr (ACC) {                          // gradient fan-in: the old values, behind the tile's MFMAs
 #pragma unroll
@@ -2286,8 +2297,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       cur = nxt;
     }
 
-    if constexpr (STATS == 2)                     // the y loads are older than this tile's NDMA instructions
-      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]) : "n"(C::NDMA));
+    if constexpr (STATS == 2) {                   // the y loads are older than this tile's NDMA instructions ...
+      if (late) asm volatile("s_waitcnt vmcnt(0)" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]));   // ... not issued yet
+      else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]) : "n"(C::NDMA));
+    }
+    if (late) {
+      if (ALWAYS || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
+    }
 
     // ---- epilogue: D of 16x16x32: column = lane & 15 (pixel), rows 4 kb + j (channel of the 16-tile).  Exactly NST
     // buffer stores per wave (an OOB offset = dropped).
@@ -2402,6 +2418,7 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   // default: the 16x16x32 kernel (conv3_ws16_kernel); UNET_WS_MFMA=3 selects the 32x32x16 one (and its staggered forms)
   // (the BatchNorm-backward form spills 9 registers in its epilogue on the new kernel and is still faster end to end:
   //  18.87 -> 18.71 ms per step)
+  P.ws_stagger = unet_tuning().ws_stg != '0';
   const bool old32 = unet_tuning().ws_mfma == '3';
   if (!old32) {
     auto k16 = P.accumulate ? conv3_ws16_kernel<true, 0>
