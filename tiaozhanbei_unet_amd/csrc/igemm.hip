@@ -2069,8 +2069,9 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
   float stat_tot = 0.f;
   const int ch0 = cg * C::ROWS + wco * 32;          // first output channel of this wave
   // (the gradient fan-in form keeps every wave's DMAs in front: its old-value loads are builtin loads, whose
-  //  compiler-placed wait would drain DMAs issued behind them)
-  const bool late = !ACC && P.ws_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
+  //  compiler-placed wait would drain DMAs issued behind them; the fused BatchNorm-backward form too: its y loads would
+  //  need a vmcnt(0) in front of the late burst and the extra code path costs it 6 more spills -- measured 605 -> 828 us/step)
+  const bool late = !ACC && STATS != 2 && P.ws_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
 
   // ---- this wave's weights -> registers: A fragment (tile ct, tap, ks) = W[ch0 + 16ct + l15][tap][32ks + 8kb .. +7]
   bf16x8 wreg[2][18];
