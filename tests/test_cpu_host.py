@@ -182,7 +182,8 @@ def test_inline_asm_dpp_reductions_keep_their_wait_states():
     """The statistics epilogues reduce over DPP rows with inline-asm v_add_f32_dpp (csrc/igemm.hip, first.hip: row16_sum_n).
     hipcc pads nothing inside an asm statement, so the helper's step-major order must leave two instructions between the
     VALU write of a value and the DPP read of it: compile both sources to assembly (gfx950 cross-compile, no GPU) and scan
-    every DPP add (tools/check_dpp_hazards.py)."""
+    every DPP add (tools/check_dpp_hazards.py).  The same scan covers the inline-asm y loads of the fused BatchNorm-backward
+    epilogues: nothing may touch a load's destination VGPRs before its hand-counted s_waitcnt."""
     import shutil
     import subprocess
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
@@ -191,6 +192,7 @@ def test_inline_asm_dpp_reductions_keep_their_wait_states():
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "igemm.hip: " in r.stdout and " 0 hazards" in r.stdout
+    assert "inline-asm y loads, 0 used before their hand-counted wait" in r.stdout, r.stdout
 
 
 def test_fused_adam_takes_a_torch_adam_state_dict():

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Static check of the inline-asm DPP reductions (row16_sum_n in csrc/igemm.hip, first.hip): hipcc pads nothing inside an asm
+"""Static checks of hand-scheduled inline asm.
+
+(1) The inline-asm DPP reductions (row16_sum_n in csrc/igemm.hip, first.hip): hipcc pads nothing inside an asm
 statement, so a `v_add_f32_dpp` must not read a VGPR that one of the two preceding instructions wrote (2 wait states).
-Compiles the two sources to assembly (hipcc -S, gfx950, no GPU needed) and scans every DPP add.
+(2) The inline-asm `buffer_load_dwordx4 ... offen` y loads of the fused BatchNorm-backward epilogues (conv3_ws16_kernel<.., 2>,
+conv3_ws_kernel<.., 2>, convt_dgrad_ws_kernel<64, true>): their only ordering against use is a hand-counted `s_waitcnt vmcnt(n)`
+dozens of MFMAs later (hipcc does not count LDS-DMAs, so its own wait would drain them).  The compiler treats the destination as
+defined right after the asm statement: no instruction between a load and the next `s_waitcnt vmcnt` may read, write, copy or spill
+any of its destination VGPRs (a register-allocator change would otherwise read them before the data lands -- silently
+wrong ReLU masks and BatchNorm-backward sums).
+Compiles the sources to assembly (hipcc -S, gfx950, no GPU needed) and scans.
 
     python tools/check_dpp_hazards.py          # exit code 1 on a hazard
 """
@@ -51,6 +59,56 @@ def scan(path):
     return n, bad
 
 
+def all_vregs(text):
+    out = set()
+    for m in re.finditer(r"v\[(\d+):(\d+)\]", text):
+        out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"(?<![a-z_\[:0-9])v(\d+)(?![\d:\]])", text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def scan_inline_loads(path, kernel_patterns):
+    """-> (loads checked, violations) over the kernels whose mangled name matches one of the patterns."""
+    n = bad = 0
+    name, body = None, []
+    kernels = {}
+    for line in open(path):
+        t = line.strip()
+        m = re.match(r"^(_Z[\w]+):", t)
+        if m:
+            name, body = m.group(1), []
+            kernels[name] = body
+        elif name and t and not t.startswith(";") and not t.startswith("."):
+            body.append(t.split(";")[0].strip())
+    for kname, ins in kernels.items():
+        if not any(pat in kname for pat in kernel_patterns):
+            continue
+        for i, t in enumerate(ins):
+            if not (t.startswith("buffer_load_dwordx4") and " offen" in t and " lds" not in t):
+                continue
+            dst = regs(t.split()[1])
+            if len(dst) != 4:
+                continue
+            n += 1
+            for u in ins[i + 1:]:
+                if u.startswith("s_waitcnt") and "vmcnt" in u:
+                    break
+                if u.endswith(":"):
+                    continue
+                if all_vregs(u) & dst and not (u.startswith("buffer_load_dwordx4") and not (regs(u.split()[1]) & dst) and not (all_vregs(" ".join(u.split()[2:])) & dst)):
+                    bad += 1
+                    print(f"EARLY USE in {kname}: `{t}` ... `{u}`")
+                    break
+            else:
+                bad += 1
+                print(f"NO WAIT after `{t}` in {kname}")
+    return n, bad
+
+
+Y_LOAD_KERNELS = ("conv3_ws16_kernelILb0ELi2E", "conv3_ws_kernelILb0ELi2E", "convt_dgrad_ws_kernelILi64ELb1E")
+
+
 def main():
     total_bad = 0
     with tempfile.TemporaryDirectory() as tmp:
@@ -61,6 +119,13 @@ def main():
             n, bad = scan(out)
             print(f"{src}: {n} DPP adds, {bad} hazards")
             total_bad += bad
+            if src == "igemm.hip":
+                n2, bad2 = scan_inline_loads(out, Y_LOAD_KERNELS)
+                print(f"{src}: {n2} inline-asm y loads, {bad2} used before their hand-counted wait")
+                total_bad += bad2
+                if n2 < 12:
+                    print("expected at least 12 inline-asm y loads (3 kernel families x 4)")
+                    total_bad += 1
     sys.exit(1 if total_bad else 0)
 
 
