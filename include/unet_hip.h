@@ -353,6 +353,13 @@ int32_t unet_seg_loss(const float* logits, const int64_t* target, int32_t n, int
 int32_t unet_seg_confusion(const float* logits, const int64_t* target, int32_t n, int32_t c, int64_t hw,
                            int64_t ignore_index, int64_t* labels, int64_t* confusion, void* stream);
 
+/* Pixel-level threshold epilogue of the anomaly branch (src/test.py:79-106 evaluate_results, src/train_utils.py:232-245
+ * validate_epoch): for each of k <= 8 thresholds the confusion counts {tp, fp, fn, tn} of (pred > t) against
+ * (truth > 0.5) over the images with select[n] != 0 (NULL: all).  counts[k][4] (int64, device) is ADDED to: zero it first.
+ * pred / truth: fp32 [n_images][per_image].  Integer atomics: exact and order-independent. */
+int32_t unet_threshold_confusion(const float* pred, const float* truth, const uint8_t* select, int64_t n_images,
+                                 int64_t per_image, const float* thresholds, int32_t k, int64_t* counts, void* stream);
+
 /* ---- nn.Dropout2d of SegmentationUNet's bottleneck (src/model.py:129,146): y = x * scale[n][c] on dense NHWC; the
  * caller draws scale = bernoulli(1-p)/(1-p) per (image, channel); the same call is the backward (dx = dy * scale). */
 int32_t unet_channel_scale(int32_t dtype, const void* x, const float* scale, int32_t n, int64_t hw, int32_t c, void* y,

@@ -212,3 +212,30 @@ def test_mvtec_loader_preprocesses_on_the_device_bit_identically(tmp_path):
         assert torch.equal(masks.cpu(), torch.stack([b["mask"] for b in hb]))
         if is_train:
             assert 0 < int(batch["flip"].sum()) < len(host), "seed 11 draws both flipped and unflipped samples"
+
+
+def test_threshold_confusion_matches_the_host_epilogue():
+    """unet_threshold_confusion (pixel metrics of src/test.py:79-106 / src/train_utils.py:232-245 on the device): counts
+    and the derived metrics equal the reference's numpy arithmetic exactly, with the anomalous-image selection, values
+    sitting exactly ON a threshold, and accumulation over batches."""
+    from tiaozhanbei_unet_amd import ops
+    from tiaozhanbei_unet_amd.utils import calculate_metrics, metrics_from_counts
+    g = torch.Generator().manual_seed(3)
+    thr = (0.3, 0.5, 0.7)
+    counts = None
+    preds, truths, labels = [], [], []
+    for b in range(3):
+        p = torch.rand(5, 1, 37, 29, generator=g)
+        p[0, 0, :4, :4] = torch.tensor(thr[b])                 # exactly on a threshold: "> t" is false
+        t = (torch.rand(5, 1, 37, 29, generator=g) < 0.1).float() / (255.0 if b == 1 else 1.0)   # {0, 1/255} masks too
+        lab = torch.tensor([1, 0, 1, 1, 0]) if b != 2 else torch.tensor([0, 0, 0, 0, 1])
+        counts = ops.threshold_confusion(p.to(DEV), t, thr, select=lab == 1, counts=counts)
+        preds.append(p[lab == 1]); truths.append(t[lab == 1])
+    got = counts.cpu().tolist()
+    P, T = torch.cat(preds).numpy(), torch.cat(truths).numpy()
+    truth = (T > 0.5).astype("uint8").ravel()
+    for (tp, fp, fn, tn), th in zip(got, thr):
+        pred = (P > th).astype("uint8").ravel()
+        want = calculate_metrics(truth, pred)
+        assert metrics_from_counts(tp, fp, fn, tn) == want, (th, got)
+        assert tp + fp + fn + tn == truth.size

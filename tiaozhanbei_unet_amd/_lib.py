@@ -98,6 +98,7 @@ SIGNATURES = {
     "unet_seg_loss_workspace": (_z, [_i, _i, _l]),
     "unet_seg_loss": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _f, _f, _f, _f, _f, _p, _p, _p, _z, _p]),
     "unet_seg_confusion": (_i, [_p, _p, _i, _i, _l, _l, _p, _p, _p]),
+    "unet_threshold_confusion": (_i, [_p, _p, _p, _l, _l, _p, _i, _p, _p]),
     "unet_channel_scale": (_i, [_i, _p, _p, _i, _l, _i, _p, _p]),
     "unet_anomaly_score_workspace": (_z, [_i, _l]),
     "unet_anomaly_score": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p, _z, _p]),

@@ -281,3 +281,48 @@ extern "C" int32_t unet_seg_confusion(const float* logits, const int64_t* target
                      c, (long long)hw, (long long)ignore_index, (long long*)labels, (unsigned long long*)confusion);
   return unet_check_launch("seg_confusion_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Pixel-level threshold epilogue of the anomaly branch (/root/reference/src/test.py:79-106 evaluate_results,
+// src/train_utils.py:232-245 validate_epoch): for each of K thresholds, the confusion counts of (anomaly_map > t)
+// against (mask > 0.5) over the selected images.  counts[k] = {tp, fp, fn, tn}; integer atomics: exact.
+namespace {
+__global__ __launch_bounds__(256) void threshold_confusion_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                                  const unsigned char* __restrict__ select, long long per_image,
+                                                                  long long total, const float* __restrict__ thr, int K,
+                                                                  unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int cnt[8 * 4];
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  float t[8];
+  for (int k = 0; k < 8; ++k) t[k] = k < K ? thr[k] : 0.f;
+  unsigned int loc[8][4] = {};
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    if (select && !select[i / per_image]) continue;
+    const float p = pred[i];
+    const bool pos = truth[i] > 0.5f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < K) loc[k][(p > t[k]) ? (pos ? 0 : 1) : (pos ? 2 : 3)] += 1;
+  }
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < 4; ++j)
+      if (loc[k][j]) atomicAdd(&cnt[k * 4 + j], loc[k][j]);
+  __syncthreads();
+  if (threadIdx.x < K * 4 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+}  // namespace
+
+extern "C" int32_t unet_threshold_confusion(const float* pred, const float* truth, const uint8_t* select, int64_t n_images,
+                                            int64_t per_image, const float* thresholds, int32_t k, int64_t* counts,
+                                            void* stream) {
+  UNET_REQUIRE(pred && truth && thresholds && counts, UNET_ERR_BAD_ARG, "unet_threshold_confusion: null pointer");
+  UNET_REQUIRE(n_images > 0 && per_image > 0 && k >= 1 && k <= 8, UNET_ERR_UNSUPPORTED,
+               "unet_threshold_confusion: %lld images, %d thresholds (1..8)", (long long)n_images, k);
+  const long long total = n_images * per_image;
+  long long gb = cdiv64(total, 256 * 8);
+  if (gb > 2048) gb = 2048;
+  hipLaunchKernelGGL(threshold_confusion_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, pred, truth, select,
+                     (long long)per_image, total, thresholds, k, (unsigned long long*)counts);
+  return unet_check_launch("threshold_confusion_kernel");
+}

@@ -983,6 +983,29 @@ class Ssim(torch.autograd.Function):
         return d1 * g, d2 * g, None, None
 
 
+def threshold_confusion(pred, truth, thresholds, select=None, counts=None):
+    """Confusion counts [K][4] = {tp, fp, fn, tn} (int64 DEVICE tensor; pass it back as ``counts`` to keep accumulating
+    over batches, read it once at the end) of (pred > t) against (truth > 0.5) for each threshold, over the images with
+    select[n] true (None: all): the pixel-metric epilogue of /root/reference/src/test.py:79-106 and
+    src/train_utils.py:232-245 on the device (unet_threshold_confusion)."""
+    _require_cuda(pred)
+    p = pred.detach().contiguous().float()
+    t = truth.detach().to(p.device).contiguous().float()
+    if p.shape != t.shape or p.dim() < 2:
+        raise ValueError("threshold_confusion: prediction / truth shapes differ")
+    n = p.shape[0]
+    per = p.numel() // n
+    thr = torch.tensor([float(v) for v in thresholds], dtype=torch.float32, device=p.device)
+    if not 1 <= thr.numel() <= 8:
+        raise ValueError("threshold_confusion: 1..8 thresholds")
+    sel = None if select is None else torch.as_tensor(select).to(device=p.device, dtype=torch.uint8).contiguous()
+    if counts is None:
+        counts = torch.zeros((thr.numel(), 4), dtype=torch.int64, device=p.device)
+    L.check(L.lib().unet_threshold_confusion(_ptr(p), _ptr(t), _ptr(sel), n, per, _ptr(thr), thr.numel(), _ptr(counts),
+                                             _stream()), "unet_threshold_confusion")
+    return counts
+
+
 def preprocess_u8(images_u8, flips=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     """uint8 [N, H, W, 3] device batch -> normalised fp32 NCHW (ToTensor + Normalize, optional per-sample horizontal
     flip): /root/reference/src/dataset.py:134-146, src/kolektorsdd_dataset.py:133-150, on the GPU."""

@@ -35,12 +35,13 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def test_model(model, test_loader, device, threshold=None):
-    from . import AnomalyUNet
+def test_model(model, test_loader, device, threshold=None, pixel_thresholds=None):
+    from . import AnomalyUNet, ops
     from .utils import compute_anomaly_score, get_optimal_threshold
     model.eval()
     out = {k: [] for k in ("images", "reconstructions", "anomaly_maps", "masks_true", "labels", "anomaly_types",
                            "image_paths", "anomaly_scores")}
+    pix = None
     with torch.no_grad():
         from .train_utils import _batches
         for batch, images, _ in _batches(test_loader, device):     # (uint8 batches are normalised on the device)
@@ -48,6 +49,9 @@ def test_model(model, test_loader, device, threshold=None):
                 recon, amap = model(images)
             else:
                 amap, recon = model(images, sigmoid=True), images      # sigmoid inside the head kernel
+            if pixel_thresholds:          # pixel-level confusion counts of the anomalous images, on the device (:86-101)
+                pix = ops.threshold_confusion(amap, batch["mask"], pixel_thresholds,
+                                              select=torch.as_tensor(np.asarray(batch["label"]) == 1), counts=pix)
             out["anomaly_scores"].extend(compute_anomaly_score(recon, images).cpu().numpy())
             out["images"].extend(images.cpu()); out["reconstructions"].extend(recon.cpu())
             out["anomaly_maps"].extend(amap.cpu().numpy()); out["masks_true"].extend(batch["mask"].numpy())
@@ -63,6 +67,8 @@ def test_model(model, test_loader, device, threshold=None):
     out["image_scores"] = out["anomaly_scores"].reshape(len(out["labels"]), -1).mean(1)
     out["predictions"] = (out["image_scores"] > threshold).astype(int)
     out["threshold"] = threshold
+    if pix is not None:
+        out["pixel_counts"] = {float(t): c for t, c in zip(pixel_thresholds, pix.cpu().tolist())}
     return out
 
 
@@ -71,7 +77,13 @@ def evaluate_results(results, pixel_thresholds):
     ev = {"image_metrics": calculate_metrics(results["labels"], results["predictions"], results["image_scores"]),
           "pixel_metrics": {}, "type_metrics": {}}
     bad = results["labels"] == 1
-    if bad.sum() > 0:
+    if bad.sum() > 0 and "pixel_counts" in results:         # counted on the device by test_model
+        from .utils import metrics_from_counts
+        for t in pixel_thresholds:
+            tp, fp, fn, tn = results["pixel_counts"][float(t)]
+            if tp + fn > 0 and fp + tn > 0:
+                ev["pixel_metrics"][f"threshold_{t}"] = metrics_from_counts(tp, fp, fn, tn)
+    elif bad.sum() > 0:
         truth = (results["masks_true"][bad] > 0.5).astype(np.uint8).ravel()
         if len(np.unique(truth)) > 1:
             for t in pixel_thresholds:
@@ -101,7 +113,7 @@ def main(argv=None):
     model = (AnomalyUNet(3, args.bilinear, precision=args.precision) if args.model == "anomaly_unet"
              else UNet(3, 1, args.bilinear, precision=args.precision)).to(device)
     load_checkpoint(model, None, args.checkpoint, device)
-    results = test_model(model, loader, device, args.threshold)
+    results = test_model(model, loader, device, args.threshold, pixel_thresholds=args.pixel_thresholds)
     ev = evaluate_results(results, args.pixel_thresholds)
     print_metrics(ev["image_metrics"], "Image-level")
 

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .utils import AverageMeter, calculate_metrics, compute_anomaly_score
+from .utils import AverageMeter, calculate_metrics, compute_anomaly_score, metrics_from_counts
 
 
 class SSIMLoss(nn.Module):
@@ -58,6 +58,9 @@ class CombinedLoss(nn.Module):
                                                       self.focal_alpha, self.focal_gamma)
         total = self.recon_weight * recon_loss + self.seg_weight * seg_loss
         return {"total_loss": total, "recon_loss": recon_loss, "seg_loss": seg_loss}
+
+
+PIXEL_THRESHOLDS = (0.3, 0.5, 0.7)          # src/train_utils.py:234
 
 
 def _batches(loader, device):
@@ -107,6 +110,7 @@ def validate_epoch(model, val_loader, criterion, device):
     model.eval()
     meters = {k: AverageMeter() for k in ("total_loss", "recon_loss", "seg_loss")}
     labels, scores, masks_true, masks_pred = [], [], [], []
+    pix_counts = None
     with torch.no_grad():
         for batch, images, masks in _batches(val_loader, device):
             reconstruction, anomaly_map = model(images)
@@ -119,6 +123,9 @@ def validate_epoch(model, val_loader, criterion, device):
             scores.extend(compute_anomaly_score(reconstruction, images).cpu().numpy())
             masks_true.extend(masks.cpu().numpy())
             masks_pred.extend(anomaly_map.cpu().numpy())
+            # pixel metrics of the anomalous images (:232-245): confusion counts at the three thresholds on the device
+            pix_counts = ops.threshold_confusion(anomaly_map, masks, PIXEL_THRESHOLDS,
+                                                 select=torch.as_tensor(np.asarray(batch["label"]) == 1), counts=pix_counts)
     labels, scores = np.array(labels), np.array(scores)
     masks_true, masks_pred = np.array(masks_true), np.array(masks_pred)
     predictions = {"labels": labels, "scores": scores, "masks_true": masks_true, "masks_pred": masks_pred}
@@ -134,13 +141,10 @@ def validate_epoch(model, val_loader, criterion, device):
                          "f1_score": 0.0, "auroc": 0.0, "auprc": 0.0}
 
     pixel_metrics = {}
-    anomalous = labels == 1
-    if anomalous.sum() > 0:
-        truth = (masks_true[anomalous] > 0.5).astype(np.uint8).ravel()
-        if len(np.unique(truth)) > 1:
-            for thr in (0.3, 0.5, 0.7):
-                pred = (masks_pred[anomalous] > thr).astype(np.uint8).ravel()
-                pixel_metrics[f"pixel_f1_@{thr}"] = calculate_metrics(truth, pred)["f1_score"]
+    if (labels == 1).sum() > 0 and pix_counts is not None:
+        for thr, (tp, fp, fn, tn) in zip(PIXEL_THRESHOLDS, pix_counts.cpu().tolist()):
+            if tp + fn > 0 and fp + tn > 0:                       # both classes among the true pixels (:241)
+                pixel_metrics[f"pixel_f1_@{thr}"] = metrics_from_counts(tp, fp, fn, tn)["f1_score"]
 
     return {"total_loss": meters["total_loss"].avg, "recon_loss": meters["recon_loss"].avg,
             "seg_loss": meters["seg_loss"].avg, "image_metrics": image_metrics, "pixel_metrics": pixel_metrics,

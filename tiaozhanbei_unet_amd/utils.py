@@ -66,6 +66,17 @@ def compute_anomaly_score(reconstruction, original, method="mse"):
     return diff.abs().mean(dim=1) if method == "l1" else (diff * diff).mean(dim=1)
 
 
+def metrics_from_counts(tp, fp, fn, tn):
+    """calculate_metrics' threshold metrics from confusion counts (the device epilogue, ops.threshold_confusion)."""
+    m = {"accuracy": (tp + tn) / max(tp + tn + fp + fn, 1),
+         "precision": tp / (tp + fp) if tp + fp else 0,
+         "recall": tp / (tp + fn) if tp + fn else 0,
+         "specificity": tn / (tn + fp) if tn + fp else 0}
+    pr = m["precision"] + m["recall"]
+    m["f1_score"] = 2 * m["precision"] * m["recall"] / pr if pr > 0 else 0
+    return m
+
+
 def calculate_metrics(y_true, y_pred, y_scores=None):
     y_true = np.asarray(y_true, dtype=int).ravel()
     y_pred = np.asarray(y_pred, dtype=int).ravel()
