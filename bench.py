@@ -259,6 +259,9 @@ def main():
                         "measured": "hipEvent brackets on the launch stream, 2 single-stream steps after the timed region",
                         "per_kernel_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
                         "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in mfma.items()},
+                        # algorithmic MB per launch of every bracket whose launcher states them (the figure PMC traffic is held against)
+                        "per_kernel_algorithmic_mb_per_launch": {k: round(v["bytes"] / v["launches"] / 1e6, 1)
+                                                                 for k, v in kern.items() if v.get("bytes")},
                         "per_class_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in prof.items() if v["launches"]},
                         "per_class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
                                              for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}}
