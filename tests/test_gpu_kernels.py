@@ -482,11 +482,17 @@ def test_batched_weight_pack_matches_single_packs(hip, dtype):
     L, ops = hip
     ws = [(rnd("pw0", (64, 3, 3, 3)), L.PACK_CONV_FWD, 64, 64), (rnd("pw0", (64, 3, 3, 3)), L.PACK_CONV_DGRAD, 64, 64),
           (rnd("pw1", (128, 64, 3, 3)), L.PACK_CONV_FWD, 128, 64), (rnd("pw1", (128, 64, 3, 3)), L.PACK_CONV_DGRAD, 64, 128),
-          (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_FWD, 64, 128), (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_DGRAD, 128, 64)]
+          (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_FWD, 64, 128), (rnd("pw2", (128, 64, 2, 2)), L.PACK_CONVT_DGRAD, 128, 64),
+          # bf16: forward + data-gradient layouts of one weight written from ONE tile read (paired path), several tiles per
+          # block column; a forward layout with no sibling behind it and a padded one take the single-layout path
+          (rnd("pw3", (256, 160, 3, 3)), L.PACK_CONV_FWD, 256, 160), (rnd("pw3", (256, 160, 3, 3)), L.PACK_CONV_DGRAD, 160, 256),
+          (rnd("pw5", (64, 96, 3, 3)), L.PACK_CONV_FWD, 64, 128), (rnd("pw5", (64, 96, 3, 3)), L.PACK_CONV_DGRAD, 128, 64),
+          (rnd("pw4", (64, 64, 3, 3)), L.PACK_CONV_FWD, 64, 64)]
     cache = ops.PackCache(dtype)
-    dev_ws = {}
-    for w, mode, rows, k in ws:
-        wd = dev_ws.setdefault(id(w), w.to(dev()))
+    dev_ws, by_shape = {}, {}
+    for w, mode, rows, k in ws:                 # the layouts of one weight share ONE device tensor (as in a model)
+        wd = by_shape.setdefault((tuple(w.shape), float(w.flatten()[0])), w.to(dev()))
+        dev_ws[id(w)] = wd
         cache.add(wd, mode, rows, k)
     cache.refresh(force=True)
     for w, mode, rows, k in ws:

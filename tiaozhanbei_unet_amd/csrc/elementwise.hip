@@ -87,9 +87,54 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // are coalesced: tile 8(a) x 64(b) when the output is contiguous along b, 64(a) x 8(b) when along a.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const unet_pack_desc* __restrict__ descs) {
-  __shared__ float tile[64 * 8 * 9 + 64];
+  __shared__ float tile[32 * 289];                 // (>= 64 * 8 * 9 + 64 of the single-layout path)
   const unet_pack_desc d = descs[blockIdx.y];
   const int mode = d.mode;
+  // PAIRED fast path (bf16, 3x3 conv, unpadded dims that are multiples of 32): the forward layout [tap][co][ci] and the
+  // data-gradient layout [8 - tap][ci][co] of one weight are consecutive descriptors; the forward descriptor's blocks
+  // write BOTH from one 32 (co) x 32 (ci) x 9 tile -- the fp32 parameter is read once instead of twice (346 -> 173 MB of
+  // reads per step); the data-gradient descriptor's blocks have nothing left to do.
+  if constexpr (sizeof(T) == 2) {
+    auto pair_ok = [](const unet_pack_desc& f, const unet_pack_desc& g) {
+      return f.mode == UNET_PACK_CONV_FWD && g.mode == UNET_PACK_CONV_DGRAD && f.w == g.w && f.c_out == g.c_out &&
+             f.c_in == g.c_in && f.rows == f.c_out && f.k == f.c_in && g.rows == g.c_in && g.k == g.c_out &&
+             (f.c_out & 31) == 0 && (f.c_in & 31) == 0;
+    };
+    if (mode == UNET_PACK_CONV_DGRAD && blockIdx.y > 0 && pair_ok(descs[blockIdx.y - 1], d)) return;
+    if (mode == UNET_PACK_CONV_FWD && blockIdx.y + 1 < gridDim.y && pair_ok(d, descs[blockIdx.y + 1])) {
+      const unet_pack_desc g = descs[blockIdx.y + 1];
+      const int Co = d.c_out, Ci = d.c_in;
+      const int nB = Ci / 32, ntile = (Co / 32) * nB;
+      const float* __restrict__ w = d.w;
+      bf16_t* __restrict__ of = reinterpret_cast<bf16_t*>(d.out);
+      bf16_t* __restrict__ og = reinterpret_cast<bf16_t*>(g.out);
+      for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int a0 = (t / nB) * 32, b0 = (t % nB) * 32;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 288; i += 256) {      // 32 rows of 288 contiguous floats (32 ci x 9 taps)
+          const int al = i / 288, r = i - al * 288;
+          tile[al * 289 + r] = w[((size_t)(a0 + al) * Ci + b0) * 9 + r];
+        }
+        __syncthreads();
+        for (int gi = threadIdx.x; gi < 2 * 32 * 9 * 4; gi += 256) {   // 16-byte stores: 8 consecutive ci (fwd) / co (dgrad)
+          const int lay = gi / (32 * 9 * 4), rem = gi % (32 * 9 * 4);
+          const int q = rem & 3, rest = rem >> 2;
+          const int tap = rest % 9, outer = rest / 9;             // outer: co (fwd) / ci (dgrad)
+          bf16x8 r8;
+          if (lay == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r8[e] = (bf16_t)tile[outer * 289 + (q * 8 + e) * 9 + tap];
+            *reinterpret_cast<bf16x8*>(of + ((size_t)tap * Co + a0 + outer) * Ci + b0 + q * 8) = r8;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r8[e] = (bf16_t)tile[(q * 8 + e) * 289 + outer * 9 + tap];
+            *reinterpret_cast<bf16x8*>(og + ((size_t)(8 - tap) * Ci + b0 + outer) * Co + a0 + q * 8) = r8;
+          }
+        }
+      }
+      return;
+    }
+  }
   const bool conv = mode <= UNET_PACK_CONV_DGRAD;
   const int taps = conv ? 9 : 4;
   const int As = conv ? d.c_out : d.c_in, Bs = conv ? d.c_in : d.c_out;     // source dims
