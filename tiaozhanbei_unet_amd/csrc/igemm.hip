@@ -55,6 +55,7 @@ struct IgemmParams {
   const float* bn_shift;
   const float* bn_mean;
   int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off)
+  int co_il;        // conv3_pdma: channel tiles interleaved per pixel tile in the work order (1, 2 or 4; see pdma_item)
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -901,6 +902,17 @@ __device__ __forceinline__ void row16_sum_n(float (&v)[N]) {
     asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v[i]) : "0"(v[i]));
 }
 
+// Work order of conv3_pdma: item wk -> (channel tile, pixel tile).  XCD x owns 32 consecutive items per round; with
+// co_il = c those are 32 / c pixel tiles x c channel tiles (super-groups of c channel tiles are walked tile-major), so the
+// c blocks that read the SAME input patches run on one L2 at the same time and the patch leaves the Infinity Cache / HBM
+// once per super-group instead of once per channel tile (c = 1: channel-tile-major, every channel tile re-streams X).
+__device__ __forceinline__ void pdma_item(int wk, int n_tiles, int c, int& cot, int& tile) {
+  const int span = c * n_tiles;
+  const int sg = wk / span, rem = wk - sg * span;
+  tile = rem / c;
+  cot = sg * c + (rem - tile * c);
+}
+
 template <int BN>
 struct CfgP {
   static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
@@ -990,7 +1002,8 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   unsigned d_wbase = 0;                          // byte offset of the work item's first weight row
   bool d_live = true;
   auto setup_dma = [&](int wk) {
-    const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
+    int cot, tile;
+    pdma_item(wk, n_tiles, P.co_il, cot, tile);
     const int n = tile / tiles_img, r = tile - n * tiles_img;
     const int ty0 = (r / P.tilesX) * C::TH, tx0 = (r % P.tilesX) * C::TW;
     d_wbase = (unsigned)(cot * BN) * P.wK * 2;
@@ -1145,7 +1158,8 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bs[ct][j] = 0.f; bq[ct][j] = 0.f; }
   for (int wk = logical; wk < total; wk += G) {
-    const int cot = wk / n_tiles, tile = wk - cot * n_tiles;
+    int cot, tile;
+    pdma_item(wk, n_tiles, P.co_il, cot, tile);
     const int n = tile / tiles_img, r = tile - n * tiles_img;
     const int tyi = r / P.tilesX, txi = r - tyi * P.tilesX;
     const int ty0 = tyi * C::TH, tx0 = txi * C::TW;
@@ -1410,8 +1424,12 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
     if (P.stats) {
       // exactly one (possibly dropped) statistics store per work item: static vmcnt counts
-      const bool flush = !P.zdiv || !has_next || (wk + G) / n_tiles != cot;
-      const int part = P.zdiv ? logical : (n * P.tilesY + tyi) * P.tilesX + txi;
+      int ncot = cot, ntile_ = 0;
+      if (has_next) pdma_item(wk + G, n_tiles, P.co_il, ncot, ntile_);
+      (void)ntile_;
+      const bool flush = !P.zdiv || !has_next || ncot != cot;
+      // block mode: the co_il blocks that share a super-group's pixel tiles own different channel tiles -> ONE partial row
+      const int part = P.zdiv ? logical / P.co_il : (n * P.tilesY + tyi) * P.tilesX + txi;
       float tsum = 0.f;
       unsigned so = OOB;
       if (!DEFER || flush) {
@@ -1523,8 +1541,16 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   const int blocks = (int)std::min<long long>(unet_cu_budget(), cdiv64(work, 8) * 8);   // one per (non-reserved) CU, a multiple of 8 (XCDs)
   const double flops = 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9;
   const long long n_tiles = (long long)P.N * P.tilesY * P.tilesX;
-  P.zdiv = (P.stats && n_tiles % blocks == 0) ? 1 : 0;       // block-mode statistics: every block visits every channel tile
-  if (P.stats && stat_parts) *stat_parts = P.zdiv ? blocks : (int)n_tiles;
+  // UNET_CONV_XCD: channel tiles interleaved per pixel tile (default: up to 4; 1 = channel-tile-major as in round 2)
+  {
+    const char xv = unet_tuning().conv_xcd;
+    const int want = xv == '1' ? 1 : (xv == '2' ? 2 : 4);
+    P.co_il = 1;
+    while (P.co_il * 2 <= want && P.nCo % (P.co_il * 2) == 0 && blocks % (P.co_il * 2 * 8) == 0) P.co_il *= 2;
+  }
+  // block-mode statistics: a block stays on one channel tile for whole super-groups and the co_il blocks of a row cover them all
+  P.zdiv = (P.stats && (n_tiles * P.co_il) % blocks == 0) ? 1 : 0;
+  if (P.stats && stat_parts) *stat_parts = P.zdiv ? blocks / P.co_il : (int)n_tiles;
 #ifdef PDMA_STAMPS
   if (!bnbwd) P.bn_mean = (const float*)g_pdma_debug;
 #endif
