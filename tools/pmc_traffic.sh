@@ -10,3 +10,4 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 UNET_TWO_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/pmc_${TAG}_MFMA -- python3 bench.py --steps 3 --warmup 2 --blocks 1 --no-cpu-baseline --no-roofline "$@" > gpurun_out/pmc_${TAG}_MFMA.log 2>&1
 python3 tools/pmc_summarize.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/pmc_${TAG}_MFMA profiles/${TAG}_pmc_traffic.json
+cp profiles/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json     # (only gpurun_out/ travels back from the GPU box)
