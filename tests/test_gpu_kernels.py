@@ -788,3 +788,40 @@ def test_conv3x3_persistent_two_source_many_work_items(hip, case):
     L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, views(L, [(x2d, 0, 0), (x1d, 0, 0)]), p(gd), co, p(dw), c0 + c1, p(ws), need,
                                        st()), "conv wgrad 2 src")
     check(dw, wq.grad, dtype, "two-source wgrad", bf=5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 17, 19, 16, 18, 0, 1), (3, 128, 128, 256, 9, 13, 8, 12, 1, 0),
+                                  (2, 64, 128, 128, 33, 40, 32, 40, 0, 0)], ids=str)
+def test_conv3x3_two_sources_with_centre_pad_offsets(hip, dtype, case):
+    """The skip-concat of Up.forward with an up-sampled tensor SMALLER than the skip (src/model.py:57-65: F.pad to the
+    skip's size, then cat): the second view sits at an offset inside the frame and is zero outside.  Forward, the
+    two-destination data gradient and the weight gradient (>= 128 output channels: wgrad16_kernel in bf16, with frame
+    widths that are not multiples of 32 and a source smaller than the frame) against F.conv2d on the padded concat."""
+    L, ops = hip
+    n, c0, c1, co, h, w, h1, w1, oy, ox = case
+    x2, x1 = rnd(f"off_x2{case}", (n, c0, h, w)), rnd(f"off_x1{case}", (n, c1, h1, w1))
+    wt = rnd(f"off_w{case}", (co, c0 + c1, 3, 3)) * (1.0 / (3 * (c0 + c1) ** 0.5))
+    gy = rnd(f"off_g{case}", (n, co, h, w))
+    x2q, x1q, wq = q(x2, dtype).requires_grad_(True), q(x1, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True)
+    x1p = F.pad(x1q, [ox, w - w1 - ox, oy, h - h1 - oy])
+    ref = F.conv2d(torch.cat([x2q, x1p], 1), wq, padding=1)
+    ref.backward(q(gy, dtype))
+    dt = ops._DT[dtype]
+    x2d, x1d, gd, wd = nhwc(x2, dtype), nhwc(x1, dtype), nhwc(gy, dtype), wt.to(dev())
+    src = views(L, [(x2d, 0, 0), (x1d, oy, ox)])
+    y = ops._nhwc_empty(n, co, h, w, dtype, dev())
+    wp = ops.pack_weight(wd, L.PACK_CONV_FWD, co, c0 + c1, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, src, p(wp), co, views(L, [(y, 0, 0), None]), co, 0, L.K_CONV_FWD, st()), "fwd")
+    check(y, ref, dtype, "two-source forward with a padded second source")
+    d2, d1 = ops._nhwc_empty(n, c0, h, w, dtype, dev()), ops._nhwc_empty(n, c1, h1, w1, dtype, dev())
+    wpd = ops.pack_weight(wd, L.PACK_CONV_DGRAD, c0 + c1, co, dtype)
+    L.check(L.lib().unet_conv3x3(dt, n, h, w, views(L, [(gd, 0, 0), None]), p(wpd), c0 + c1,
+                                 views(L, [(d2, 0, 0), (d1, oy, ox)]), c0, 0, L.K_CONV_DGRAD, st()), "dgrad")
+    check(d2, x2q.grad, dtype, "dgrad, skip half")
+    check(d1, x1q.grad, dtype, "dgrad, up-sampled half (cropped back to its own size)")
+    dw = torch.empty(co, c0 + c1, 3, 3, device=dev())
+    need = L.lib().unet_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    L.check(L.lib().unet_conv3x3_wgrad(dt, n, h, w, src, p(gd), co, p(dw), c0 + c1, p(ws), need, st()), "wgrad")
+    check(dw, wq.grad, dtype, "wgrad over a padded second source", f32=5e-5, bf=5e-3)
