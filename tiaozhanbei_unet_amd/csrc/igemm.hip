@@ -2290,6 +2290,9 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
     bf16x8 ring[RING2 ? 2 : 1][4];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) ring[0][pt] = frag(0, pt);
+#ifdef WS16_NO_MFMA           // diagnostic build: the tile's DMAs / stores / barriers without its MFMAs and fragment reads
+    if (false)
+#endif
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
       if constexpr (RING2) {
@@ -2402,7 +2405,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
       const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
 #pragma unroll
-      for (int q = 0; q < NVIEW; ++q) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][q], 0, 0);
+      for (int q = 0; q < NVIEW; ++q) {
+#ifdef WS16_NO_STORE          // diagnostic build: every store dropped (out-of-range offset), counts unchanged
+        __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], OOB, 0, 0);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][q], 0, 0);
+#endif
+      }
     }
     if constexpr (STATS != 0) {
       // the DPP row is the 16 pixels of a tile row: one reduction leaves a (statistic, channel) total of this wave's
