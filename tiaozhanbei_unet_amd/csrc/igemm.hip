@@ -56,6 +56,7 @@ struct IgemmParams {
   const float* bn_mean;
   int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off)
   int co_il;        // conv3_pdma: channel tiles interleaved per pixel tile in the work order (1, 2 or 4; see pdma_item)
+  int pdma_stagger; // conv3_pdma (lock-step): DMA issues of a SIMD's two waves at opposite ends of a tap
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -1144,6 +1145,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #endif
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
   bool after_epilogue = false;
+  const bool late_dma = !PP && P.pdma_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
   // BatchNorm partial sums of this lane's outputs (4 channels x CT tiles, 2 statistics).  Block mode (P.zdiv: every
   // block visits every channel tile): a layer of thousands of tiles has 256 partials to finalise -- the block keeps a
   // running total per (statistic, channel) over its work items of one channel tile.  BN = 64 (DEFER): the per-lane sums
@@ -1262,16 +1264,25 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
         st_sum[1] += st_c - st_b;
 #endif
-        if (tap < C::NDA) dma_patch(last ? 0 : c + 1, tap, pbuf_i ^ 1, last ? d_live : true);
-        if (tap + 2 < 9) dma_w(c_wbase, c, tap + 2, (tap + 2) % 3, true);
-        else if (!last) dma_w(c_wbase, c + 1, tap + 2 - 9, (tap + 2) % 3, true);
-        else dma_w(d_wbase, 0, tap + 2 - 9, (tap + 2) % 3, d_live);
+        // This tap's DMA issues (a patch piece of the next chunk, the weight slab two taps ahead).  The two waves of a SIMD
+        // (w, w + 4) issue at opposite ends of the tap -- waves 4-7 here, waves 0-3 behind their MFMAs -- so that one of
+        // them has MFMAs to issue while the other sits in its burst (UNET_PDMA_STG=0: all eight behind the barrier, as in
+        // round 2).  The per-wave ORDER of vector-memory operations is unchanged, so every counted vmcnt above still holds;
+        // a slot is refilled after the barrier that follows its last reads either way.
+        auto issue_dma = [&]() {
+          if (tap < C::NDA) dma_patch(last ? 0 : c + 1, tap, pbuf_i ^ 1, last ? d_live : true);
+          if (tap + 2 < 9) dma_w(c_wbase, c, tap + 2, (tap + 2) % 3, true);
+          else if (!last) dma_w(c_wbase, c + 1, tap + 2 - 9, (tap + 2) % 3, true);
+          else dma_w(d_wbase, 0, tap + 2 - 9, (tap + 2) % 3, d_live);
+        };
+        if (!late_dma) issue_dma();
 #ifdef PDMA_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
         st_sum[2] += st_prev - st_c;
         st_taps += 1;
 #endif
         compute(pbuf, (tap / 3) * C::RS + (tap % 3) * C::PSTR, tap % 3);
+        if (late_dma) issue_dma();
       }
       }
       pbuf_i ^= 1;
@@ -1524,6 +1535,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   // the ping-pong schedule wins where a work item is long (>= 8 chunks: +2 % at 512, +6 % at 1024 input channels) and
   // loses where the epilogue -- run once per half, each exposed -- is a large part of an item (-10 % at 128 channels);
   // UNET_PDMA_PP=0 / 1 force lock-step / ping-pong
+  P.pdma_stagger = unet_tuning().pdma_stg != '0';           // default on: +3..8 % on the lock-step layers (profiles/r03_pdma_stagger.txt)
   const char ppv = unet_tuning().pdma_pp;
   const bool pp = ppv == '1' || (ppv != '0' && BN == 128 && P.Ctot >= 512);
   auto kern = pp ? (bnbwd ? (BN == 128 ? conv3_pp128_bnbwd_kernel : conv3_pp64_bnbwd_kernel)
