@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (median reported)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 32 (unet: 16)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--height", type=int, default=None, help="non-square frames (BASELINE configs[4]: --height 1408 --width 512)")
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--model", default="anomaly_unet", choices=["anomaly_unet", "unet"])
     ap.add_argument("--precision", default=None, choices=["bf16", "fp32"], help="default bf16 (unet: fp32, configs[1])")
     ap.add_argument("--ssim", action="store_true", help="SSIM reconstruction head instead of MSE (configs[2] --use_ssim)")
@@ -156,11 +158,12 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
     n, s = args.batch, args.size
-    images = torch.randn(n, 3, s, s, device=dev, generator=g)
+    fh, fw = args.height or s, args.width or s
+    images = torch.randn(n, 3, fh, fw, device=dev, generator=g)
     if args.mask == "bernoulli":
-        masks = (torch.rand(n, 1, s, s, device=dev, generator=g) < 0.02).float()
+        masks = (torch.rand(n, 1, fh, fw, device=dev, generator=g) < 0.02).float()
     else:
-        masks = torch.zeros(n, 1, s, s, device=dev)
+        masks = torch.zeros(n, 1, fh, fw, device=dev)
 
     def step():
         recon, amap = net(images)
@@ -203,7 +206,7 @@ def main():
 
     # ---- roofline of the dominant kernel: hipEvent brackets inside libunet_hip, 2 extra steps
     roof = None
-    default_cfg = (args.model == "anomaly_unet" and args.precision == "bf16" and args.batch == 32 and args.size == 256
+    default_cfg = (args.model == "anomaly_unet" and args.precision == "bf16" and args.batch == 32 and args.size == 256 and not args.height and not args.width
                    and not args.ssim and args.mask == "bernoulli")
     if not args.no_roofline:
         # (every rank runs the two extra steps -- they contain the gradient collectives; only rank 0 brackets them)
@@ -278,16 +281,17 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
-        scale = (s * s) / 65536.0
+        scale = (fh * fw) / 65536.0
+        sz = f"{fh}x{fw}"
         train_tflops = 3 * FWD_GFLOP_PER_IMG_256[args.model] * scale * value / 1e3
         if args.model == "anomaly_unet":
-            metric = f"training images/sec, AnomalyUNet {s}x{s} bs={args.batch} per GPU"
+            metric = f"training images/sec, AnomalyUNet {sz} bs={args.batch} per GPU"
             loss_name = "SSIM+focal loss (--use_ssim)" if args.ssim else "MSE+focal loss"
-            workload = (f"AnomalyUNet 3x{s}x{s}, bs={args.batch}/GPU, {loss_name}, Adam (BASELINE.json configs[2], "
+            workload = (f"AnomalyUNet 3x{sz}, bs={args.batch}/GPU, {loss_name}, Adam (BASELINE.json configs[2], "
                         f"synthetic randn images, {args.mask} masks)")
         else:
-            metric = f"training images/sec, UNet(3,1) {s}x{s} bs={args.batch} per GPU (seg-only)"
-            workload = (f"UNet(3,1) 3x{s}x{s}, bs={args.batch}/GPU, focal loss on sigmoid(logits), Adam (BASELINE.json "
+            metric = f"training images/sec, UNet(3,1) {sz} bs={args.batch} per GPU (seg-only)"
+            workload = (f"UNet(3,1) 3x{sz}, bs={args.batch}/GPU, focal loss on sigmoid(logits), Adam (BASELINE.json "
                         f"configs[1], synthetic randn images, {args.mask} masks)")
         out = {
             "metric": metric, "value": round(value, 2),
