@@ -51,10 +51,20 @@ def main():
     net.finish_gradients()
     torch.cuda.synchronize()
     step2_same = all(torch.equal(v.grad.cpu(), grads[k]) for k, v in model.named_parameters())
+    # ... and on both ranks, with ONE bucket layout (rank 0's completion order was broadcast before the rebuild)
+    flat2 = torch.cat([v.grad.reshape(-1) for v in model.parameters()])
+    other2 = [torch.empty_like(flat2) for _ in range(2)]
+    dist.all_gather(other2, flat2)
+    index = {id(p): i for i, p in enumerate(model.parameters())}
+    layout = torch.tensor([index[id(p)] for ps in net.exchange._bucket_plan() for p in ps], dtype=torch.int64, device=dev)
+    layouts = [torch.empty_like(layout) for _ in range(2)]
+    dist.all_gather(layouts, layout)
+    ranks_equal2 = bool(torch.equal(other2[0], other2[1])) and bool(torch.equal(layouts[0], layouts[1]))
     if rank == 0:
         torch.save({"grads": grads, "ranks_equal": same, "bucket_mb": net.exchange.bucket_sizes_mb(),
                     "in_place": bool(in_place), "copies": int(net.exchange.copies), "copies_step1": int(copies_step1),
-                    "reordered": bool(net.exchange._reordered), "step2_same": bool(step2_same)}, sys.argv[1])
+                    "reordered": bool(net.exchange._reordered), "step2_same": bool(step2_same),
+                    "ranks_equal_step2": ranks_equal2}, sys.argv[1])
     dist.destroy_process_group()
 
 

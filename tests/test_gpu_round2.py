@@ -320,6 +320,7 @@ def test_data_parallel_gradients_equal_mean_of_shard_gradients(tmp_path):
     # buckets were re-laid in the completion order of step 1 without changing the result
     assert got["in_place"] and got["copies"] == 0, got
     assert got["reordered"] and got["step2_same"], got
+    assert got["ranks_equal_step2"], "after the rebuild the ranks disagree (gradients or bucket layout)"
 
 
 def test_gpu_preprocess_is_bit_identical_to_host_transform():
