@@ -268,6 +268,13 @@ def main():
                         "per_class_ms_per_step": {k: round(v["ms"] / 2, 3) for k, v in prof.items() if v["launches"]},
                         "per_class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
                                              for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}}
+                # BASELINE.json's target reads "MFMA utilisation on 3x3 DoubleConv fwd+bwd": the three conv3x3 classes'
+                # FLOPs over THEIR bracketed kernel time (statistics epilogues and split-K reductions included, the
+                # BatchNorm-apply / pooling passes not), next to the whole-step figure below
+                c3 = [v for k, v in prof.items() if k.startswith("conv3x3_") and v["flops"] > 0 and v["ms"] > 0]
+                if c3:
+                    roof["conv3x3_fwd_bwd_mfma_frac_of_peak_kernel_time"] = round(
+                        sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12 / peak, 4)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

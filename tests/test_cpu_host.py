@@ -193,6 +193,10 @@ def test_inline_asm_dpp_reductions_keep_their_wait_states():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "igemm.hip: " in r.stdout and " 0 hazards" in r.stdout
     assert "inline-asm y loads, 0 used before their hand-counted wait" in r.stdout, r.stdout
+    # ... and the kernels whose vmcnt waits are hand-counted over an exact DMA / load / store sequence do not spill (a scratch
+    # access would be one more operation in that sequence)
+    assert "igemm.hip: 12 kernels with hand-counted vmcnt waits, 0 with scratch traffic" in r.stdout, r.stdout
+    assert "wgrad.hip: 2 kernels with hand-counted vmcnt waits, 0 with scratch traffic" in r.stdout, r.stdout
 
 
 def test_fused_adam_takes_a_torch_adam_state_dict():

@@ -215,7 +215,10 @@ def test_conv3x3_first_layer_kernels(hip, case):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("geom", [(1, 64, 64, 64, 17, 19, 16, 16), (2, 64, 64, 64, 32, 16, 16, 16),
-                                  (1, 128, 128, 128, 16, 32, 16, 32)], ids=str)
+                                  (1, 128, 128, 128, 16, 32, 16, 32),
+                                  # dense 16-aligned frames, 64 gradient channels: the two-destination (and gradient
+                                  # fan-in) forms of conv3_ws16_kernel, several tiles per block
+                                  (2, 64, 64, 64, 32, 48, 32, 48), (9, 64, 64, 64, 64, 64, 64, 64)], ids=str)
 def test_conv3x3_concat_and_centre_pad_views(hip, dtype, geom):
     """cat([x2, pad(x1)]) (model.py:57-65) expressed as two source views, and the matching
     two-destination data gradient (odd frame: register-staged kernels; 16-aligned frames: LDS-DMA kernels)."""

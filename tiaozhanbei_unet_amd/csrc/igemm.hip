@@ -54,7 +54,7 @@ struct IgemmParams {
   const float* bn_scale;
   const float* bn_shift;
   const float* bn_mean;
-  int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off)
+  int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off, 1: without the deferred stores)
   int co_il;        // conv3_pdma: channel tiles interleaved per pixel tile in the work order (1, 2 or 4; see pdma_item)
   int pdma_stagger; // conv3_pdma (lock-step): DMA issues of a SIMD's two waves at opposite ends of a tap
 };
@@ -2110,6 +2110,11 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
   //  compiler-placed wait would drain DMAs issued behind them; the fused BatchNorm-backward form too: its y loads would
   //  need a vmcnt(0) in front of the late burst and the extra code path costs it 6 more spills -- measured 605 -> 828 us/step)
   const bool late = !ACC && STATS != 2 && P.ws_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
+  // ... and the other half (waves 4-7) keeps a tile's packed results in registers across the barrier and stores them at
+  // the top of the NEXT tile, behind its DMA burst: every vector-memory instruction of a wave is then issued while its
+  // SIMD partner runs MFMAs (a store or DMA that waits for a queue slot stalls the wave that issues it, and at the old
+  // tile end both waves of a SIMD stalled together).  UNET_WS_STG=1: the DMA placement without the deferred stores.
+  const bool defer = !ACC && STATS != 2 && P.ws_stagger >= 2 && __builtin_amdgcn_readfirstlane(wave) >= 4;
 
   // ---- this wave's weights -> registers: A fragment (tile ct, tap, ks) = W[ch0 + 16ct + l15][tap][32ks + 8kb .. +7]
   bf16x8 wreg[2][18];
@@ -2134,16 +2139,18 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
 #pragma unroll
   for (int b = 0; b < 8; ++b) vb[b] = (unsigned)((wpx * 4 * C::HW + l15) * 128 + ((kb ^ ((b + l15) & 7)) << 4));
   const DView S = P.src[0];
-  // DMA descriptors, two to a register: hy | hx << 5 | source piece << 10 | 1 << 14 (0: beyond the patch)
-  unsigned a_pk[(C::NDMA + 1) / 2];
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  // DMA lane offsets relative to the patch origin (tile-invariant): lane q of instruction j fetches piece pos ^ (pp & 7)
+  // of patch pixel pp = q >> 3 (beyond the patch: dropped).  The tile enters through the descriptor's base address
+  // (scalar arithmetic), so an interior tile costs no vector instruction per DMA; a tile on the frame's edge checks its
+  // halo pixels per lane.
+  unsigned a_rel[C::NDMA];
 #pragma unroll
   for (int j = 0; j < C::NDMA; ++j) {
     const int q = (j * C::NWAVE + wave) * 64 + lane;
     const int pp = q >> 3, pos = q & 7;
     const int hy = pp / C::HW, hx = pp - hy * C::HW;
-    const unsigned code = pp < C::NPIXP ? (unsigned)(hy | (hx << 5) | ((pos ^ (pp & 7)) << 10) | (1 << 14)) : 0u;
-    if (j & 1) a_pk[j >> 1] |= code << 16;
-    else a_pk[j >> 1] = code;
+    a_rel[j] = pp < C::NPIXP ? (unsigned)((hy * S.W + hx) * S.C * 2 + ((pos ^ (pp & 7)) << 4)) : OOB;
   }
   const unsigned img_bytes = (unsigned)S.H * S.W * S.C * 2u;
 
@@ -2166,20 +2173,33 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
 
   auto dma_a = [&](int buf, bool live) {         // the patch of the tile at dma_it (then advance); dead = to the dummy KiB
     const int ym1 = dma_it.ty * 16 - 1, xm1 = dma_it.tx * 16 - 1;
-    const unsigned base = (unsigned)((ym1 * S.W + xm1) * S.C * 2);      // (may wrap below zero: only valid sums are used)
+    // base = the patch origin (it may lie in front of the image: only lanes of pixels inside the frame carry an offset
+    // below num_records; a valid lane's offset stays below 18 rows of the frame)
+    const long long org = ((long long)ym1 * S.W + xm1) * (S.C * 2);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(S.p + (size_t)(live ? dma_it.n : 0) * img_bytes), (short)0, (int)img_bytes, 0x00020000);
+        (void*)(S.p + (long long)(live ? dma_it.n : 0) * img_bytes + org), (short)0, 0x7FFFFFF0, 0x00020000);
+    const bool inner = live && ym1 >= 0 && xm1 >= 0 && ym1 + C::HH <= S.H && xm1 + C::HW <= S.W;
+    if (inner) {
 #pragma unroll
-    for (int j = 0; j < C::NDMA; ++j) {
-      unsigned code = (a_pk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-      asm volatile("" : "+v"(code));               // decode per tile (hoisted out of the loop it costs live registers)
-      const int hy = code & 31, hx = (code >> 5) & 31, part = (code >> 10) & 15;
-      const unsigned y = (unsigned)(ym1 + hy), x = (unsigned)(xm1 + hx);
-      const bool ok = live && (code >> 14) && y < (unsigned)S.H && x < (unsigned)S.W;
-      const unsigned vo = ok ? base + (unsigned)((hy * S.W + hx) * S.C * 2 + part * 16) : OOB;
-      const int idx = j * C::NWAVE + wave;                          // wave-uniform
-      char* dst = (live && idx < C::NINSTR) ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, 0, 0, 0);
+      for (int j = 0; j < C::NDMA; ++j) {
+        const int idx = j * C::NWAVE + wave_s;
+        char* dst = idx < C::NINSTR ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, a_rel[j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C::NDMA; ++j) {
+        int q = (j * C::NWAVE + wave_s) * 64 + lane;
+        asm volatile("" : "+v"(q));                 // (per tile: hoisted out of the loop it costs live registers)
+        const int pp = q >> 3;
+        const int hy = pp / C::HW, hx = pp - hy * C::HW;
+        const unsigned y = (unsigned)(ym1 + hy), x = (unsigned)(xm1 + hx);
+        const bool ok = live && y < (unsigned)S.H && x < (unsigned)S.W;
+        const unsigned vo = ok ? a_rel[j] : OOB;
+        const int idx = j * C::NWAVE + wave_s;
+        char* dst = (live && idx < C::NINSTR) ? smem + buf * C::A_BYTES + idx * 1024 : smem + C::DUMMY;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, 0, 0, 0);
+      }
     }
     tile_next(dma_it);
   };
@@ -2190,9 +2210,32 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
   static_assert(2 * NST + C::NDMA + NY <= 63, "vmcnt range");
   constexpr bool ALWAYS = STATS == 2;            // that form always issues its NDMA instructions: one wait form
 
+  // Dense frames only (the launcher sends everything else to conv3_ws_kernel): whole 16x16 tiles, every destination view
+  // covers the frame at offset 0.  A lane's offset inside a tile never changes (ovb: pixel row 0 of its four, per view;
+  // rows 1-3 through the scalar offset operand, which the range check ignores: a lane that does not store carries an
+  // out-of-range offset) and the tile enters through the descriptors' base addresses: scalar arithmetic only, where the
+  // general lane geometry was ~200 vector instructions per tile.
   __amdgpu_buffer_rsrc_t drs[2];
-  unsigned ovo[4][NVIEW];
+  unsigned ovb[NVIEW];
+  u32x4 pend[4];                                 // deferred stores: the packed results of the previous tile
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) pend[pt] = u32x4{0u, 0u, 0u, 0u};
+  {
+    const int co = ch0 + (kb & 1) * 16 + (kb >> 1) * 8;       // after the swap a lane holds 8 consecutive channels: tile (kb & 1), channels 8 (kb >> 1) .. + 7
+#pragma unroll
+    for (int q = 0; q < NVIEW; ++q) {
+      const DViewW D = P.dst[q];
+      const int cq = q == 0 ? co : co - P.dst_split;
+      const bool mine = (q == 0) == (co < P.dst_split);
+      ovb[q] = mine ? (unsigned)(((wpx * 4 * D.W + l15) * D.C + cq) * 2) : OOB;     // (an absent second view arrives as a copy of the first: no lane is its)
+    }
+  }
+  // (tile 0's deferred group: NST stores against empty descriptors -- dropped, same vmcnt arithmetic)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)P.dst[0].p, (short)0, 0, 0x00020000);
+  const unsigned rowb[2] = {(unsigned)(P.dst[0].W * P.dst[0].C * 2), (unsigned)(P.dst[1].W * P.dst[1].C * 2)};   // bytes per pixel row
   int n_img = 0;
+  unsigned soff0 = 0;                            // byte offset of the tile in view 0 (the y loads add it too)
   auto geometry = [&]() {                        // of the tile at geo_it (then advance)
     const int n = geo_it.n;
     const int ty0 = geo_it.ty * 16, tx0 = geo_it.tx * 16;
@@ -2202,24 +2245,9 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
     for (int q = 0; q < 2; ++q) {
       const DViewW D = P.dst[q];
       const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
-      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p ? D.p + (size_t)n * dimg : P.dst[0].p), (short)0,
-                                                 D.p ? (int)dimg : 0, 0x00020000);
-    }
-    // after the swap a lane holds 8 consecutive channels: tile (kb & 1), channels 8 (kb >> 1) .. + 7
-    const int co = ch0 + (kb & 1) * 16 + (kb >> 1) * 8;
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
-      const bool pix_ok = fy < P.H && fx < P.W;
-#pragma unroll
-      for (int q = 0; q < NVIEW; ++q) {             // one store per destination view; the other one is OOB
-        const DViewW D = P.dst[q];
-        const int cq = q == 0 ? co : co - P.dst_split;
-        const bool mine = (q == 0) == (co < P.dst_split);
-        const int y = fy - D.oy, x = fx - D.ox;
-        const bool ok = mine && pix_ok && D.p && y >= 0 && y < D.H && x >= 0 && x < D.W;
-        ovo[pt][q] = ok ? (unsigned)(((y * D.W + x) * D.C + cq) * 2) : OOB;
-      }
+      const unsigned so = (unsigned)((ty0 * D.W + tx0) * D.C * 2);
+      if (q == 0) soff0 = so;
+      drs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p + (size_t)n * dimg + so), (short)0, (int)(dimg - so), 0x00020000);
     }
   };
   auto take_slots = [&](int kk) {                // the four pixel-wave slots of tile kk -> this thread's running total
@@ -2234,6 +2262,13 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
   for (int d = 0; d < C::NBUF - 1; ++d)
     if (ALWAYS || t_begin + d < t_end) dma_a(d, t_begin + d < t_end);
   int cur = 0;
+#ifdef PDMA_STAMPS
+  unsigned long long w6_st[6] = {0, 0, 0, 0, 0, 0}, w6_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long w6_t0 = w6_prev, w6_r0 = __builtin_amdgcn_s_memrealtime();
+#define W6_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); w6_st[i] += t_ - w6_prev; w6_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define W6_STAMP(i)
+#endif
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int k = tile - t_begin;
     const bool next_in_flight = ALWAYS || tile + 1 < t_end;
@@ -2249,40 +2284,57 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    W6_STAMP(0)
     __builtin_amdgcn_s_barrier();
+    W6_STAMP(1)
     if (k >= 1) take_slots(k - 1);
+    constexpr bool RING2 = !ACC && STATS != 2;
+    if constexpr (RING2) {
+      // per-wave order of vector-memory operations in a tile: DMA(k + 2), then ONE group of NST stores -- tile k's own
+      // at its end (waves 0-3 and the lock-step form) or tile k - 1's here (waves 4-7): the counted waits above hold for both
+      if (!late) {
+        if (tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, true);
+      }
+      if (defer) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+          for (int q = 0; q < NVIEW; ++q) __builtin_amdgcn_raw_buffer_store_b128(pend[pt], drs[q], ovb[q], pt * rowb[q], 0);
+      }
+    }
     geometry();
     const int n = n_img;
     (void)n;
     u32x4 yv[STATS == 2 ? 4 : 1];
     if constexpr (STATS == 2) {
       const unsigned dimg = (unsigned)P.dst[0].H * P.dst[0].W * P.dst[0].C * 2u;
-      const __amdgpu_buffer_rsrc_t yrs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(P.bn_y + (size_t)n * dimg), (short)0, (int)dimg, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(P.bn_y + (size_t)n * dimg + soff0), (short)0, (int)(dimg - soff0), 0x00020000);
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt)             // inline asm + hand-counted wait (hipcc does not count LDS-DMAs)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(yv[pt]) : "v"(ovo[pt][0]), "s"(yrs) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(yv[pt]) : "v"(ovb[0]), "s"(yrs), "s"(pt * rowb[0]) : "memory");
     }
     // The patch DMAs of tile k + 2.  A wave inside its burst of six one-KiB issues feeds no MFMAs, and with all eight
     // waves bursting behind the barrier the matrix pipe idles for the whole burst (r02 stamps: the burst costs as much
     // as the tile's 72 MFMAs).  The two waves of a SIMD (w, w + 4) therefore issue at opposite ends of the tile: waves
     // 4-7 here, waves 0-3 -- the older ones, which win the SIMD's issue arbitration and so should compute first -- behind
     // their MFMAs, still in front of the tile's stores (the vmcnt bookkeeping above counts the same operations either way).
-    if (!late) {
+    if constexpr (!RING2) {
       if (ALWAYS || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
     }
     u32x4 oldv[ACC ? 4 : 1];
     if constexpr (ACC) {                          // gradient fan-in: the old values, behind the tile's MFMAs
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) {
-        const bool second = ovo[pt][0] == OOB;
+        const bool second = ovb[0] == OOB;
         const bool want = (P.accumulate >> (second ? 1 : 0)) & 1;
-        const unsigned vo = want ? (second ? ovo[pt][NVIEW - 1] : ovo[pt][0]) : OOB;
-        oldv[pt] = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
-                          : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
+        const unsigned vo = want ? (second ? ovb[NVIEW - 1] : ovb[0]) : OOB;
+        oldv[pt] = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, pt * rowb[1], 0)
+                          : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, pt * rowb[0], 0);
       }
     }
 
+    W6_STAMP(2)
     f32x4 acc[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -2298,7 +2350,6 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
     };
     // (the forms that hold y / old values across the loop have 16 registers fewer: ONE fragment set, each fragment
     //  re-requested for the next step right behind the two MFMAs that read it -- six MFMAs of cover)
-    constexpr bool RING2 = !ACC && STATS != 2;
     bf16x8 ring[RING2 ? 2 : 1][4];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) ring[0][pt] = frag(0, pt);
@@ -2330,6 +2381,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
         }
       }
     }
+    W6_STAMP(3)
     // the ring slot of the next tile
     {
       const int nxt = (cur + 1) % C::NBUF;
@@ -2347,19 +2399,10 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       if (ALWAYS || tile + C::NBUF - 1 < t_end) dma_a((k + C::NBUF - 1) % C::NBUF, tile + C::NBUF - 1 < t_end);
     }
 
+    W6_STAMP(4)
     // ---- epilogue: D of 16x16x32: column = lane & 15 (pixel), rows 4 kb + j (channel of the 16-tile).  Exactly NST
     // buffer stores per wave (an OOB offset = dropped).
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 csc[2], csh[2], cmu[2];
-    if constexpr (STATS == 2) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int cb = wco * 32 + 16 * t + 4 * kb;
-        csc[t] = *reinterpret_cast<const f32x4*>(ctab + cb);
-        csh[t] = *reinterpret_cast<const f32x4*>(ctab + 64 + cb);
-        cmu[t] = *reinterpret_cast<const f32x4*>(ctab + 128 + cb);
-      }
-    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       float va[4], vv[4];
@@ -2380,15 +2423,24 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
         const auto o1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
         const bf16x4 ya = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
         const bf16x4 yb = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
-        const bool ok = ovo[pt][0] != OOB;        // a tile pixel outside the frame: no sums
+        // (dense frames: every tile pixel is a frame pixel.)  The 3 x 4 coefficients of a channel half are re-read from
+        // LDS per pixel row and half -- 12 live registers instead of 24 in a kernel that must not spill: scratch traffic
+        // inside the loop would join the hand-counted vmcnt stream
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float fa = (float)ya[j], fb = (float)yb[j];
-          ra[j] = (bf16_t)((ok && fmaf(fa, csc[0][j], csh[0][j]) > 0.f) ? va[j] : 0.f);
-          rb[j] = (bf16_t)((ok && fmaf(fb, csc[1][j], csh[1][j]) > 0.f) ? vv[j] : 0.f);
-          const float q0 = (float)ra[j], q1 = (float)rb[j];                  // dz as stored
-          sa[j] += q0; qa[j] = fmaf(q0, fa - cmu[0][j], qa[j]);
-          sb[j] += q1; qb[j] = fmaf(q1, fb - cmu[1][j], qb[j]);
+        for (int t = 0; t < 2; ++t) {
+          asm volatile("" ::: "memory");
+          const int cb = wco * 32 + 16 * t + 4 * kb;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(ctab + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(ctab + 64 + cb);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(ctab + 128 + cb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float fy = (float)(t ? yb[j] : ya[j]);
+            const bf16_t r = (bf16_t)(fmaf(fy, sc[j], sh[j]) > 0.f ? (t ? vv[j] : va[j]) : 0.f);
+            const float q0 = (float)r;                                         // dz as stored
+            if (t) { rb[j] = r; sb[j] += q0; qb[j] = fmaf(q0, fy - mu[j], qb[j]); }
+            else { ra[j] = r; sa[j] += q0; qa[j] = fmaf(q0, fy - mu[j], qa[j]); }
+          }
         }
       } else {
         if (P.bias) {                              // inference: BatchNorm shift (+ ReLU) of the folded layer
@@ -2403,7 +2455,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ra[j] = (bf16_t)va[j]; rb[j] = (bf16_t)vv[j]; }
         if constexpr (STATS == 1) {
-          const bool ok = ovo[pt][0] != OOB;
+          constexpr bool ok = true;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float q0 = ok ? (float)ra[j] : 0.f, q1 = ok ? (float)rb[j] : 0.f;   // the values as stored
@@ -2416,13 +2468,16 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
       const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
       const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      pend[pt] = bits;             // (unconditional: dead across the MFMA loop for the register allocator)
+      if (!defer) {
 #pragma unroll
-      for (int q = 0; q < NVIEW; ++q) {
+        for (int q = 0; q < NVIEW; ++q) {
 #ifdef WS16_NO_STORE          // diagnostic build: every store dropped (out-of-range offset), counts unchanged
-        __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], OOB, 0, 0);
 #else
-        __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovo[pt][q], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(bits, drs[q], ovb[q], pt * rowb[q], 0);
 #endif
+        }
       }
     }
     if constexpr (STATS != 0) {
@@ -2441,13 +2496,34 @@ __global__ __launch_bounds__(512, 1) void conv3_ws16_kernel(const IgemmParams P,
         }
       }
     }
+    W6_STAMP(5)
+  }
+#ifdef PDMA_STAMPS
+  if (STATS != 2 && P.bn_mean && lane == 0) {
+    unsigned long long* o = (unsigned long long*)P.bn_mean + ((size_t)(blockIdx.x & 255) * 8 + wave) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = w6_st[i];
+    o[6] = ((__builtin_amdgcn_s_memtime() - w6_t0) << 20) / (__builtin_amdgcn_s_memrealtime() - w6_r0 + 1);
+    o[7] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
+  if (defer) {                                   // the last tile's results
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int q = 0; q < NVIEW; ++q) __builtin_amdgcn_raw_buffer_store_b128(pend[pt], drs[q], ovb[q], pt * rowb[q], 0);
   }
   if constexpr (STATS != 0) {
-    // the last tile's slots, then ONE partial per block
+    // the last tile's slots, then ONE partial per block.  (The thread index is re-derived here: values computed from the
+    // launch-time one before the loop would be spilled across it, and scratch traffic joins the hand-counted vmcnt stream.)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    take_slots(t_end - 1 - t_begin);
-    if (tid < 128) P.stats[((size_t)tr * 2 + (tid >> 6)) * P.Cout + cg * C::ROWS + (tid & 63)] = stat_tot;
+    const int tid2 = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (tid2 < 128) {
+      const float* rp = red + ((t_end - 1 - t_begin) & 1) * 512 + (tid2 >> 6) * 256 + (tid2 & 63);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) stat_tot += rp[sl * 64];
+      P.stats[((size_t)tr * 2 + (tid2 >> 6)) * P.Cout + cg * C::ROWS + (tid2 & 63)] = stat_tot;
+    }
   }
   if constexpr (ALWAYS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMAs before the wave ends
 }
@@ -2466,9 +2542,13 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   // default: the 16x16x32 kernel (conv3_ws16_kernel); UNET_WS_MFMA=3 selects the 32x32x16 one (and its staggered forms)
   // (the BatchNorm-backward form spills 9 registers in its epilogue on the new kernel and is still faster end to end:
   //  18.87 -> 18.71 ms per step)
-  P.ws_stagger = unet_tuning().ws_stg != '0';
+  P.ws_stagger = unet_tuning().ws_stg == '0' ? 0 : (unet_tuning().ws_stg == '1' ? 1 : 2);
   const bool old32 = unet_tuning().ws_mfma == '3';
-  if (!old32) {
+  bool dense16 = P.H % 16 == 0 && P.W % 16 == 0;
+  for (int q = 0; q < 2; ++q)
+    if (P.dst[q].p && (P.dst[q].oy || P.dst[q].ox || P.dst[q].H != P.H || P.dst[q].W != P.W)) dense16 = false;
+  if (!old32 && dense16) {          // (ragged frames / offset views: conv3_ws_kernel's per-lane geometry)
+    if (!P.dst[1].p) P.dst[1] = P.dst[0];         // no lane stores to it (dst_split == Cout); saves the kernel a select per tile
     auto k16 = P.accumulate ? conv3_ws16_kernel<true, 0>
                             : (mode == 2 ? conv3_ws16_kernel<false, 2> : (mode == 1 ? conv3_ws16_kernel<false, 1> : conv3_ws16_kernel<false, 0>));
     P.tilesX = cdiv(P.W, 16);
@@ -2485,6 +2565,9 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
     ProfScope prof(kclass, 2.0 * P.N * P.H * P.W * (double)P.Cout * P.Ctot * 9, s,
                    mode == 2 ? "conv3_ws_bnbwd_kernel" : "conv3_ws_kernel",
                    2.0 * (px16 * (P.Ctot + P.Cout * (1.0 + (mode == 2 ? 1 : 0) + (P.accumulate ? 1 : 0))) + 9.0 * P.Ctot * P.Cout));
+#ifdef PDMA_STAMPS
+    if (mode != 2) P.bn_mean = (const float*)g_pdma_debug;
+#endif
     hipLaunchKernelGGL(k16, dim3((unsigned)(ranges * nCg16)), dim3(512), CfgWS16::LDS, s, P, tpb16);
     return unet_check_launch("conv3_ws16_kernel");
   }

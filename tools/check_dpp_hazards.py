@@ -9,6 +9,8 @@ dozens of MFMAs later (hipcc does not count LDS-DMAs, so its own wait would drai
 defined right after the asm statement: no instruction between a load and the next `s_waitcnt vmcnt` may read, write, copy or spill
 any of its destination VGPRs (a register-allocator change would otherwise read them before the data lands -- silently
 wrong ReLU masks and BatchNorm-backward sums).
+(3) Kernels with hand-counted `s_waitcnt vmcnt(n)` (the LDS-DMA convolution / weight-gradient kernels) must not spill: scratch traffic
+would join the counted stream (scan_no_scratch).
 Compiles the sources to assembly (hipcc -S, gfx950, no GPU needed) and scans.
 
     python tools/check_dpp_hazards.py          # exit code 1 on a hazard
@@ -106,6 +108,29 @@ def scan_inline_loads(path, kernel_patterns):
     return n, bad
 
 
+def scan_no_scratch(path, kernel_patterns):
+    """-> (kernels checked, kernels with scratch traffic).  Kernels whose waits are hand-counted `s_waitcnt vmcnt(n)` over an exact
+    per-tile sequence of DMAs, loads and stores must not spill: a scratch_load / scratch_store is one more vector-memory operation
+    in that sequence, and a count that is too lax lets a wave read an LDS patch whose DMA has not landed (round 3: a 14-spill
+    build of conv3_ws16_kernel<false, 2> passed every small-frame test and produced garbage gradients at 32 tiles per block)."""
+    n = bad = 0
+    name = None
+    for line in open(path):
+        t = line.strip()
+        m = re.match(r"^(_Z[\w]+):", t)
+        if m:
+            name = m.group(1) if any(pat in m.group(1) for pat in kernel_patterns) else None
+            n += name is not None
+            seen = False
+        elif name and t.startswith("scratch_") and not seen:
+            seen = True
+            bad += 1
+            print(f"SPILL in {name}: `{t.split(';')[0].strip()}`")
+    return n, bad
+
+
+NO_SPILL_KERNELS = ("conv3_ws16_kernel", "conv3_pdma", "conv3_pp", "wgrad16_kernelILi2ELi1E")
+
 Y_LOAD_KERNELS = ("conv3_ws16_kernelILb0ELi2E", "conv3_ws_kernelILb0ELi2E", "convt_dgrad_ws_kernelILi64ELb1E")
 
 
@@ -126,6 +151,15 @@ def main():
                 if n2 < 12:
                     print("expected at least 12 inline-asm y loads (3 kernel families x 4)")
                     total_bad += 1
+                n3, bad3 = scan_no_scratch(out, NO_SPILL_KERNELS)
+                print(f"{src}: {n3} kernels with hand-counted vmcnt waits, {bad3} with scratch traffic")
+                total_bad += bad3 + (n3 < 12)
+        out = os.path.join(tmp, "wgrad.hip.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S",
+                               "--cuda-device-only", os.path.join(ROOT, "tiaozhanbei_unet_amd", "csrc", "wgrad.hip"), "-o", out])
+        n3, bad3 = scan_no_scratch(out, NO_SPILL_KERNELS)
+        print(f"wgrad.hip: {n3} kernels with hand-counted vmcnt waits, {bad3} with scratch traffic")
+        total_bad += bad3 + (n3 < 2)
     sys.exit(1 if total_bad else 0)
 
 
