@@ -218,7 +218,8 @@ def test_conv3x3_first_layer_kernels(hip, case):
                                   (1, 128, 128, 128, 16, 32, 16, 32),
                                   # dense 16-aligned frames, 64 gradient channels: the two-destination (and gradient
                                   # fan-in) forms of conv3_ws16_kernel, several tiles per block
-                                  (2, 64, 64, 64, 32, 48, 32, 48), (9, 64, 64, 64, 64, 64, 64, 64)], ids=str)
+                                  (2, 64, 64, 64, 32, 48, 32, 48), (9, 64, 64, 64, 64, 64, 64, 64),
+                                  (24, 64, 64, 64, 64, 64, 64, 64)], ids=str)      # 768 tiles x 2 channel groups: six per block
 def test_conv3x3_concat_and_centre_pad_views(hip, dtype, geom):
     """cat([x2, pad(x1)]) (model.py:57-65) expressed as two source views, and the matching
     two-destination data gradient (odd frame: register-staged kernels; 16-aligned frames: LDS-DMA kernels)."""
@@ -508,7 +509,10 @@ def test_batched_weight_pack_matches_single_packs(hip, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("case", [(2, 64, 64, 24, 40), (2, 128, 128, 16, 24), (1, 128, 64, 9, 20), (3, 256, 128, 8, 8),
-                                  (1, 64, 128, 9, 21), (4, 64, 64, 128, 144)],
+                                  (1, 64, 128, 9, 21), (4, 64, 64, 128, 144),
+                                  # 640 / 1152 tiles of conv3_ws16_kernel on <= 256 blocks: three and five tiles per block -- the
+                                  # steady state of its 3-slot ring, the hand-counted waits and the deferred stores
+                                  (40, 64, 64, 64, 64), (18, 64, 128, 128, 64)],
                          ids=str)
 def test_conv3x3_fused_bn_statistics(hip, dtype, case):
     """unet_conv3x3_stats: the conv epilogue's wavefront-reduced partial sums (weight-stationary kernel, 16x16x32
@@ -613,6 +617,7 @@ DGRAD_BN_CASES = [  # n, c_dy, c_dx, h, w  -- two have > 256 work items per laun
     # 64 -> 64 runs on the weight-stationary streaming kernel (any frame size, several tiles per block, empty tile ranges)
     (2, 128, 128, 16, 32), (1, 256, 64, 32, 16), (3, 128, 256, 16, 16), (8, 128, 128, 128, 128), (5, 128, 64, 64, 96),
     (2, 64, 64, 24, 40), (1, 64, 64, 9, 21), (4, 64, 64, 128, 144),
+    (40, 64, 64, 64, 64),       # conv3_ws16_kernel<false, 2>: 640 tiles, three per block (ring / counted-wait steady state)
     # >= 512 gradient channels: the ping-pong instantiation (conv3_pp128_bnbwd_kernel) with several work items per block --
     # 320 items on 256 blocks (ragged last round, per-tile partials) and 512 items (block-mode partials, two channel tiles)
     (20, 512, 512, 32, 32), (16, 512, 256, 64, 64)]
