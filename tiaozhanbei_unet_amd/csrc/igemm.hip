@@ -57,6 +57,7 @@ struct IgemmParams {
   int ws_stagger;   // conv3_ws16_kernel: the two waves of a SIMD issue their patch DMAs at opposite ends of a tile (UNET_WS_STG=0: off, 1: without the deferred stores)
   int co_il;        // conv3_pdma: channel tiles interleaved per pixel tile in the work order (1, 2 or 4; see pdma_item)
   int pdma_stagger; // conv3_pdma (lock-step): DMA issues of a SIMD's two waves at opposite ends of a tap
+  int pdma_dense;   // conv3_pdma: every destination view covers the frame at offset 0 (scalar output addressing)
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -1153,6 +1154,16 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   // + LDS exchange + barrier leave the per-item epilogue: +3 %); at BN = 128 the 32 extra live registers spill (-5 %),
   // so there every item reduces and a thread carries the total.  Fixed order either way: deterministic.
   constexpr bool DEFER = BN == 64;
+  // Output addressing of dense destinations (P.pdma_dense: every destination view covers the frame at offset 0; frames are
+  // whole 16x16 tiles here anyway): a lane's offset inside a (tile, 32-channel pair) never changes -- lp[view]: pixel row 0
+  // of its four; rows 1-3 through the scalar offset operand, which the range check ignores -- and the work item enters
+  // through the descriptor's base address.  Scalar arithmetic per item instead of ~25 vector instructions per store in
+  // an epilogue that all eight waves run together (stamps: 10-20 % of a 128/256-channel layer's launch).
+  const bool dense = BNBWD || P.pdma_dense != 0;
+  unsigned lp[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    lp[q] = (unsigned)((((wpx * 4) * P.dst[q].W + l15) * P.dst[q].C + (kb & 1) * 16 + (kb >> 1) * 8) * 2);
   float stat_tot = 0.f;
   float bs[C::CT][4], bq[C::CT][4];
 #pragma unroll
@@ -1318,19 +1329,20 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
           __builtin_amdgcn_make_buffer_rsrc((void*)(P.bn_y + (size_t)n * dimg), (short)0, (int)dimg, 0x00020000);
       u32x4 yraw[4][C::CT / 2];
       f32x4 csc[C::CT / 2][2], csh[C::CT / 2][2], cmu[C::CT / 2][2];
-      unsigned vo4[4][C::CT / 2];
+      (void)yrs;
+      const unsigned rowb = (unsigned)(D.W * D.C * 2);
+      __amdgpu_buffer_rsrc_t yrs_c[C::CT / 2], drs_c[C::CT / 2];
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
-        const bool ok = fy < P.H && fx < P.W;
-#pragma unroll
-        for (int cp = 0; cp < C::CT / 2; ++cp) {
-          const int cw = co0 + wco * (BN / 2) + cp * 32;
-          const int co = cw + (kb & 1) * 16 + (kb >> 1) * 8;
-          vo4[pt][cp] = ok ? (unsigned)(((fy * D.W + fx) * D.C + co) * 2) : OOB;
-          yraw[pt][cp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, vo4[pt][cp], 0, 0);
-        }
+      for (int cp = 0; cp < C::CT / 2; ++cp) {
+        const int cw = co0 + wco * (BN / 2) + cp * 32;
+        const unsigned off = (unsigned)(((ty0 * D.W + tx0) * D.C + cw) * 2);
+        yrs_c[cp] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.bn_y + (size_t)n * dimg + off), (short)0, (int)(dimg - off), 0x00020000);
+        drs_c[cp] = __builtin_amdgcn_make_buffer_rsrc((void*)(D.p + (size_t)n * dimg + off), (short)0, (int)(dimg - off), 0x00020000);
       }
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int cp = 0; cp < C::CT / 2; ++cp) yraw[pt][cp] = __builtin_amdgcn_raw_buffer_load_b128(yrs_c[cp], lp[0], pt * rowb, 0);
 #pragma unroll
       for (int cp = 0; cp < C::CT / 2; ++cp) {
         const int cw = co0 + wco * (BN / 2) + cp * 32 + kb * 4;   // native layout: tile 2cp rows kb*4.., +16: tile 2cp+1
@@ -1367,7 +1379,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
           const u32x2 ua = __builtin_bit_cast(u32x2, ra), ub = __builtin_bit_cast(u32x2, rb);
           const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, drs[0], vo4[pt][cp], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, drs_c[cp], lp[0], pt * rowb, 0);
         }
       }
     } else {
@@ -1375,60 +1387,80 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     // holds 8 CONSECUTIVE channels -- tile ct + (kb & 1), channels 8*(kb >> 1) .. +7 -- and writes 16 bytes (half
     // the store instructions, 64 contiguous bytes per pixel and tile pair).  Old values for the gradient fan-in
     // come in with the same 16-byte loads and are un-swapped (the exchange is an involution) before the fp32 add.
+    // (pt, cp): the wave's pixel row and 32-channel tile pair; rs / vo / so: descriptor, lane offset, scalar offset of its store
+    auto finish = [&](int pt, int cp, int cw, bool second, int accq, __amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so, bool ok) {
+      float va[4], vb[4];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
-      const bool pix_ok = fy < P.H && fx < P.W;
+      for (int j = 0; j < 4; ++j) { va[j] = acc[2 * cp][pt][j]; vb[j] = acc[2 * cp + 1][pt][j]; }
+      if (P.bias) {                                // inference: BatchNorm shift (+ ReLU) of the folded layer
+        const float* bp = P.bias + cw + kb * 4;   // native accumulator layout: tile 2cp (+16: tile 2cp+1), rows kb*4..+3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] += bp[j]; vb[j] += bp[16 + j]; }
+      }
+      if (P.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = fmaxf(va[j], 0.f); vb[j] = fmaxf(vb[j], 0.f); }
+      }
+      if (accq) {
+        const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+        const auto o0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+        const auto o1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+        const bf16x4 oa = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
+        const bf16x4 ob = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] += (float)oa[j]; vb[j] += (float)ob[j]; }
+      }
+      bf16x4 ra, rb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ra[j] = (bf16_t)va[j]; rb[j] = (bf16_t)vb[j]; }
+      const u32x2 ua = __builtin_bit_cast(u32x2, ra), ub = __builtin_bit_cast(u32x2, rb);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, so, 0);
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {              // statistics of the values as STORED (bf16-rounded)
+          const float qa = (float)ra[j], qb = (float)rb[j];
+          bs[2 * cp][j] += qa;
+          bq[2 * cp][j] = fmaf(qa, qa, bq[2 * cp][j]);
+          bs[2 * cp + 1][j] += qb;
+          bq[2 * cp + 1][j] = fmaf(qb, qb, bq[2 * cp + 1][j]);
+        }
+      }
+    };
+    if (dense) {
 #pragma unroll
       for (int cp = 0; cp < C::CT / 2; ++cp) {
         const int cw = co0 + wco * (BN / 2) + cp * 32;               // first channel of the tile pair
         const bool second = cw >= P.dst_split;                       // uniform per (wave, pair): dst_split % 64 == 0
         const int accq = second ? (P.accumulate & 2) : (P.accumulate & 1);
         const DViewW D = second ? P.dst[1] : P.dst[0];
-        const int co = cw - (second ? P.dst_split : 0) + (kb & 1) * 16 + (kb >> 1) * 8;
-        const int y = fy - D.oy, x = fx - D.ox;
-        const bool ok = pix_ok && y >= 0 && y < D.H && x >= 0 && x < D.W;
-        const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + co) * 2) : OOB;
-        float va[4], vb[4];
+        const unsigned dimg = (unsigned)D.H * D.W * D.C * 2u;
+        const unsigned off = (unsigned)(((ty0 * D.W + tx0) * D.C + cw - (second ? P.dst_split : 0)) * 2);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(D.p + (size_t)n * dimg + off), (short)0, (int)(dimg - off), 0x00020000);
+        const unsigned rowb = (unsigned)(D.W * D.C * 2);
+        const unsigned lpq = second ? lp[1] : lp[0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { va[j] = acc[2 * cp][pt][j]; vb[j] = acc[2 * cp + 1][pt][j]; }
-        if (P.bias) {                                // inference: BatchNorm shift (+ ReLU) of the folded layer
-          const float* bp = P.bias + cw + kb * 4;   // native accumulator layout: tile 2cp (+16: tile 2cp+1), rows kb*4..+3
+        for (int pt = 0; pt < 4; ++pt) finish(pt, cp, cw, second, accq, rs, lpq, pt * rowb, true);
+      }
+    } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { va[j] += bp[j]; vb[j] += bp[16 + j]; }
-        }
-        if (P.relu) {
+      for (int pt = 0; pt < 4; ++pt) {
+        const int fy = ty0 + wpx * 4 + pt, fx = tx0 + l15;
+        const bool pix_ok = fy < P.H && fx < P.W;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { va[j] = fmaxf(va[j], 0.f); vb[j] = fmaxf(vb[j], 0.f); }
-        }
-        if (accq) {
-          const u32x4 o = second ? __builtin_amdgcn_raw_buffer_load_b128(drs[1], vo, 0, 0)
-                                 : __builtin_amdgcn_raw_buffer_load_b128(drs[0], vo, 0, 0);
-          const auto o0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
-          const auto o1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
-          const bf16x4 oa = __builtin_bit_cast(bf16x4, u32x2{o0[0], o1[0]});
-          const bf16x4 ob = __builtin_bit_cast(bf16x4, u32x2{o0[1], o1[1]});
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { va[j] += (float)oa[j]; vb[j] += (float)ob[j]; }
-        }
-        bf16x4 ra, rb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ra[j] = (bf16_t)va[j]; rb[j] = (bf16_t)vb[j]; }
-        const u32x2 ua = __builtin_bit_cast(u32x2, ra), ub = __builtin_bit_cast(u32x2, rb);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-        const u32x4 bits = u32x4{s0[0], s1[0], s0[1], s1[1]};
-        if (second) __builtin_amdgcn_raw_buffer_store_b128(bits, drs[1], vo, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(bits, drs[0], vo, 0, 0);
-        if (ok) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {              // statistics of the values as STORED (bf16-rounded)
-            const float qa = (float)ra[j], qb = (float)rb[j];
-            bs[2 * cp][j] += qa;
-            bq[2 * cp][j] = fmaf(qa, qa, bq[2 * cp][j]);
-            bs[2 * cp + 1][j] += qb;
-            bq[2 * cp + 1][j] = fmaf(qb, qb, bq[2 * cp + 1][j]);
-          }
+        for (int cp = 0; cp < C::CT / 2; ++cp) {
+          const int cw = co0 + wco * (BN / 2) + cp * 32;               // first channel of the tile pair
+          const bool second = cw >= P.dst_split;                       // uniform per (wave, pair): dst_split % 64 == 0
+          const int accq = second ? (P.accumulate & 2) : (P.accumulate & 1);
+          const DViewW D = second ? P.dst[1] : P.dst[0];
+          const int co = cw - (second ? P.dst_split : 0) + (kb & 1) * 16 + (kb >> 1) * 8;
+          const int y = fy - D.oy, x = fx - D.ox;
+          const bool ok = pix_ok && y >= 0 && y < D.H && x >= 0 && x < D.W;
+          const unsigned vo = ok ? (unsigned)(((y * D.W + x) * D.C + co) * 2) : OOB;
+          if (second) finish(pt, cp, cw, true, accq, drs[1], vo, 0u, ok);
+          else finish(pt, cp, cw, false, accq, drs[0], vo, 0u, ok);
         }
       }
     }
@@ -1535,6 +1567,9 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   // the ping-pong schedule wins where a work item is long (>= 8 chunks: +2 % at 512, +6 % at 1024 input channels) and
   // loses where the epilogue -- run once per half, each exposed -- is a large part of an item (-10 % at 128 channels);
   // UNET_PDMA_PP=0 / 1 force lock-step / ping-pong
+  P.pdma_dense = unet_tuning().pdma_stg != '2';             // (UNET_PDMA_STG=2: the per-lane output geometry, for A/B)
+  for (int q = 0; q < 2; ++q)
+    if (P.dst[q].p && (P.dst[q].oy || P.dst[q].ox || P.dst[q].H != P.H || P.dst[q].W != P.W)) P.pdma_dense = 0;
   P.pdma_stagger = unet_tuning().pdma_stg != '0';           // default on: +3..8 % on the lock-step layers (profiles/r03_pdma_stagger.txt)
   const char ppv = unet_tuning().pdma_pp;
   const bool pp = ppv == '1' || (ppv != '0' && BN == 128 && P.Ctot >= 512);
