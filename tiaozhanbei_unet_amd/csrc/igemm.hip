@@ -944,6 +944,9 @@ struct CfgP {
 // lock-step tap went to the DMA issue burst, profiles/r02_pdma_stamps.txt).  LDS hazards at distance one barrier: a
 // slab / patch buffer is re-filled by DMAs issued in the slot after its last reads, which are retired (lgkmcnt(0))
 // BEFORE the barrier that ends their LOAD.
+#ifndef PDMA_DEFER128
+#define PDMA_DEFER128 (!PP && !BNBWD)
+#endif
 template <int BN, bool BNBWD = false, bool PP = false>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   using C = CfgP<BN>;
@@ -1151,9 +1154,11 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   // block visits every channel tile): a layer of thousands of tiles has 256 partials to finalise -- the block keeps a
   // running total per (statistic, channel) over its work items of one channel tile.  BN = 64 (DEFER): the per-lane sums
   // themselves run on across those items and are reduced over lanes and waves ONCE, at the last of them (the 64 DPP adds
-  // + LDS exchange + barrier leave the per-item epilogue: +3 %); at BN = 128 the 32 extra live registers spill (-5 %),
-  // so there every item reduces and a thread carries the total.  Fixed order either way: deterministic.
-  constexpr bool DEFER = BN == 64;
+  // + LDS exchange + barrier leave the per-item epilogue: +3 %).  At BN = 128 that is 32 more live registers: the lock-step
+  // forward kernel has them since the output addressing went scalar (215 -> 247 VGPRs, +0..4 % per layer,
+  // profiles/r03_pdma_dense_epilogue.txt); the ping-pong and BatchNorm-backward instantiations (251 / 236) would spill, so
+  // there every item reduces and a thread carries the total.  Fixed order either way: deterministic.
+  constexpr bool DEFER = BN == 64 || PDMA_DEFER128;
   // Output addressing of dense destinations (P.pdma_dense: every destination view covers the frame at offset 0; frames are
   // whole 16x16 tiles here anyway): a lane's offset inside a (tile, 32-channel pair) never changes -- lp[view]: pixel row 0
   // of its four; rows 1-3 through the scalar offset operand, which the range check ignores -- and the work item enters
