@@ -1422,7 +1422,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, so, 0);
-      if (ok) {
+      if (ok && P.stats) {                         // (a launch without statistics skips the 24 vector instructions per store)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {              // statistics of the values as STORED (bf16-rounded)
           const float qa = (float)ra[j], qb = (float)rb[j];
