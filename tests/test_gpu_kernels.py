@@ -512,7 +512,9 @@ def test_batched_weight_pack_matches_single_packs(hip, dtype):
                                   (1, 64, 128, 9, 21), (4, 64, 64, 128, 144),
                                   # 640 / 1152 tiles of conv3_ws16_kernel on <= 256 blocks: three and five tiles per block -- the
                                   # steady state of its 3-slot ring, the hand-counted waits and the deferred stores
-                                  (40, 64, 64, 64, 64), (18, 64, 128, 128, 64)],
+                                  (40, 64, 64, 64, 64), (18, 64, 128, 128, 64),
+                                  # a ragged frame of the same class: conv3_ws_kernel (per-lane geometry), three tiles per block
+                                  (6, 64, 64, 200, 136)],
                          ids=str)
 def test_conv3x3_fused_bn_statistics(hip, dtype, case):
     """unet_conv3x3_stats: the conv epilogue's wavefront-reduced partial sums (weight-stationary kernel, 16x16x32
@@ -618,6 +620,7 @@ DGRAD_BN_CASES = [  # n, c_dy, c_dx, h, w  -- two have > 256 work items per laun
     (2, 128, 128, 16, 32), (1, 256, 64, 32, 16), (3, 128, 256, 16, 16), (8, 128, 128, 128, 128), (5, 128, 64, 64, 96),
     (2, 64, 64, 24, 40), (1, 64, 64, 9, 21), (4, 64, 64, 128, 144),
     (40, 64, 64, 64, 64),       # conv3_ws16_kernel<false, 2>: 640 tiles, three per block (ring / counted-wait steady state)
+    (6, 64, 64, 200, 136),      # ragged frame: conv3_ws_kernel<false, 2>, 702 tiles, three per block
     # >= 512 gradient channels: the ping-pong instantiation (conv3_pp128_bnbwd_kernel) with several work items per block --
     # 320 items on 256 blocks (ragged last round, per-tile partials) and 512 items (block-mode partials, two channel tiles)
     (20, 512, 512, 32, 32), (16, 512, 256, 64, 64)]
