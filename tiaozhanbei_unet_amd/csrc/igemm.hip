@@ -58,6 +58,7 @@ struct IgemmParams {
   int co_il;        // conv3_pdma: channel tiles interleaved per pixel tile in the work order (1, 2 or 4; see pdma_item)
   int pdma_stagger; // conv3_pdma (lock-step): DMA issues of a SIMD's two waves at opposite ends of a tap
   int pdma_dense;   // conv3_pdma: every destination view covers the frame at offset 0 (scalar output addressing)
+  int pdma_dense_src; // conv3_pdma: every source view covers the frame at offset 0, one channel stride (scalar patch addressing)
 };
 
 constexpr int TH = 8, TW = 16, NPIX = TH * TW;
@@ -984,7 +985,9 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     const int q = (j * 8 + wave) * 64 + lane;
     const int pix = q / C::PPP, part = q - pix * C::PPP;
     const int hy = pix / C::HW, hx = pix - hy * C::HW;
-    a_code[j] = (pix < C::HH * C::HW && part < 8) ? (hy | (hx << 8) | (part << 16)) : -1;
+    // bits 24-27: the pixel lies in the patch's top / bottom row, left / right column (the halo of a frame-edge tile)
+    const int edge = (hy == 0) | ((hy == C::HH - 1) << 1) | ((hx == 0) << 2) | ((hx == C::HW - 1) << 3);
+    a_code[j] = (pix < C::HH * C::HW && part < 8) ? (hy | (hx << 8) | (part << 16) | (edge << 24)) : -1;
   }
   unsigned w_g[C::NDW];
 #pragma unroll
@@ -1006,12 +1009,36 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   __amdgpu_buffer_rsrc_t a_rsrc[2];
   unsigned d_wbase = 0;                          // byte offset of the work item's first weight row
   bool d_live = true;
+  // Dense sources (P.pdma_dense_src: both views frame-sized at offset 0, one channel stride): a lane's patch offsets
+  // relative to the patch origin never change -- kept in a_g[1][], which the general path uses for the second view -- and
+  // the work item enters through the descriptors' base addresses; per item only the halo of a frame-edge tile is masked
+  // (3 vector instructions per piece instead of ~17 x 2 views, in the last chunk's taps where issue slots are scarce).
+  const bool dsrc = P.pdma_dense_src != 0;
+  if (dsrc) {
+#pragma unroll
+    for (int j = 0; j < C::NDA; ++j) {
+      const int code = a_code[j];
+      const int hy = code & 255, hx = (code >> 8) & 255, part = (code >> 16) & 255;
+      a_g[1][j] = code >= 0 ? (unsigned)(((hy * P.src[0].W + hx) * P.src[0].C) * 2 + part * 16) : OOB;
+    }
+  }
   auto setup_dma = [&](int wk) {
     int cot, tile;
     pdma_item(wk, n_tiles, P.co_il, cot, tile);
     const int n = tile / tiles_img, r = tile - n * tiles_img;
     const int ty0 = (r / P.tilesX) * C::TH, tx0 = (r % P.tilesX) * C::TW;
     d_wbase = (unsigned)(cot * BN) * P.wK * 2;
+    if (dsrc) {
+      const unsigned E = (unsigned)((ty0 == 0) | ((ty0 + C::TH == P.H) << 1) | ((tx0 == 0) << 2) | ((tx0 + C::TW == P.W) << 3)) << 24;
+      // (the patch origin of a top / left tile lies in front of the image: only in-frame lanes carry an in-range offset)
+      const long long tb = ((long long)(ty0 - 1) * P.src[0].W + (tx0 - 1)) * (P.src[0].C * 2);
+      a_rsrc[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[0].p + (long long)n * img0 + tb), (short)0, 0x7FFFFFF0, 0x00020000);
+      a_rsrc[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[1].p ? P.src[1].p + (long long)n * img1 + tb : P.src[0].p),
+                                                    (short)0, P.src[1].p ? 0x7FFFFFF0 : 0, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < C::NDA; ++j) a_g[0][j] = ((unsigned)a_code[j] & E) ? OOB : a_g[1][j];
+      return;
+    }
     a_rsrc[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[0].p + (size_t)n * img0), (short)0, (int)img0, 0x00020000);
     a_rsrc[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(P.src[1].p ? P.src[1].p + (size_t)n * img1 : P.src[0].p),
                                                   (short)0, P.src[1].p ? (int)img1 : 0, 0x00020000);
@@ -1038,7 +1065,11 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[0], (lds_void*)dst, 16, live ? a_g[0][j] : OOB,
                                                (unsigned)ch * 2, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[1], (lds_void*)dst, 16, live ? a_g[1][j] : OOB,
+      // (the two candidates pass through an opaque copy: folded into a load through a selected POINTER they would take the
+      //  whole a_g array out of registers -- scratch traffic inside the hand-counted vmcnt stream)
+      unsigned o0 = a_g[0][j], o1 = a_g[1][j];
+      asm volatile("" : "+v"(o0), "+v"(o1));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc[1], (lds_void*)dst, 16, live ? (dsrc ? o0 : o1) : OOB,
                                                (unsigned)(ch - P.src[0].C) * 2, 0, 0);
     }
   };
@@ -1573,6 +1604,11 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   // loses where the epilogue -- run once per half, each exposed -- is a large part of an item (-10 % at 128 channels);
   // UNET_PDMA_PP=0 / 1 force lock-step / ping-pong
   P.pdma_dense = unet_tuning().pdma_stg != '2';             // (UNET_PDMA_STG=2: the per-lane output geometry, for A/B)
+  P.pdma_dense_src = unet_tuning().pdma_stg != '2' && unet_tuning().pdma_stg != '4';      // (4: per-lane patch geometry only)
+  for (int k = 0; k < 2; ++k)
+    if (P.src[k].p && P.src[k].C > 0 &&
+        (P.src[k].oy || P.src[k].ox || P.src[k].H != P.H || P.src[k].W != P.W || P.src[k].C != P.src[0].C))
+      P.pdma_dense_src = 0;
   for (int q = 0; q < 2; ++q)
     if (P.dst[q].p && (P.dst[q].oy || P.dst[q].ox || P.dst[q].H != P.H || P.dst[q].W != P.W)) P.pdma_dense = 0;
   P.pdma_stagger = unet_tuning().pdma_stg != '0';           // default on: +3..8 % on the lock-step layers (profiles/r03_pdma_stagger.txt)
