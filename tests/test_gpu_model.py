@@ -148,9 +148,12 @@ def test_full_model_forward_bf16_documented_bound(sz):
     m.eval()
     with torch.no_grad():
         recon, amap = m(x)
-    assert maxabs(recon, g["eval_out0"]) < 3e-2 and maxabs(amap, g["eval_out1"]) < 3e-2
-    agree = ((amap.cpu() > 0.5) == (g["eval_out1"] > 0.5)).float().mean()
-    assert float(agree) > 0.97
+    agree = float(((amap.cpu() > 0.5) == (g["eval_out1"] > 0.5)).float().mean())
+    print(f"[bf16 forward {sz}] max|recon err| {maxabs(recon, g['eval_out0']):.3e}  max|amap err| "
+          f"{maxabs(amap, g['eval_out1']):.3e}  mask agreement {agree:.4f}")
+    # SURVEY section 4's suggested bound (2e-2 abs, >= 98 % thresholded-mask agreement)
+    assert maxabs(recon, g["eval_out0"]) < 2e-2 and maxabs(amap, g["eval_out1"]) < 2e-2
+    assert agree >= 0.98
 
 
 def test_training_trajectory_matches_reference():
