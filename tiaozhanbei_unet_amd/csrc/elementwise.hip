@@ -355,13 +355,67 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
     sc[j] = scale[g * PIECE + j]; sh[j] = shift[g * PIECE + j]; mu[j] = mean[g * PIECE + j];
     s0[j] = 0.f; s1[j] = 0.f;
   }
-  for (idx_t i = (idx_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (idx_t)gridDim.x * 256) {
-    idx_t t = i / G;
-    const int ox = (int)(t % WW);  t /= WW;
-    const int oy = (int)(t % WH);
-    const idx_t n = t / WH;
+  // The window walk advances by a fixed stride of windows per iteration: its (image, row, column) decomposition is
+  // computed once and carried (no divisions in the loop; the element-wise work is what limits this pass).
+  const idx_t i0 = (idx_t)blockIdx.x * 256 + threadIdx.x;
+  idx_t t0 = i0 / G;
+  int ox = (int)(t0 % WW);  t0 /= WW;
+  int oy = (int)(t0 % WH);
+  idx_t n = t0 / WH;
+  idx_t ts = ((idx_t)gridDim.x * 256) / G;       // (256 % G == 0: every thread keeps its channel group)
+  const int sx = (int)(ts % WW);  ts /= WW;
+  const int sy = (int)(ts % WH);
+  const idx_t sn = ts / WH;
+  for (idx_t i = i0; i < total; i += (idx_t)gridDim.x * 256) {
     const idx_t base = ((n * H + 2 * oy) * W + 2 * ox) * (idx_t)C + g * PIECE;
     const bool ex = 2 * ox + 1 < W, ey = 2 * oy + 1 < H, full = oy < OH && ox < OW;
+    if (ex && ey) {
+      // whole window (every window of an even frame): straight-line code, selects instead of branches.  Same values
+      // and the same accumulation order (window position 0..3 per channel) as the general path below.
+      const idx_t o1 = base + C, o2 = base + (idx_t)W * C, o3 = o2 + C;
+      float gr[PIECE], yv[4][PIECE], od[4][PIECE];
+      Vec<T>::load(dpooled + (((n * OH + oy) * OW + ox) * (idx_t)C + g * PIECE), gr);
+      Vec<T>::load(y + base, yv[0]);
+      Vec<T>::load(y + o1, yv[1]);
+      Vec<T>::load(y + o2, yv[2]);
+      Vec<T>::load(y + o3, yv[3]);
+      if (da_old) {
+        Vec<T>::load(da_old + base, od[0]);
+        Vec<T>::load(da_old + o1, od[1]);
+        Vec<T>::load(da_old + o2, od[2]);
+        Vec<T>::load(da_old + o3, od[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < PIECE; ++j) od[k][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        float z[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          z[k] = fmaf(yv[k][j], sc[j], sh[j]);
+          a[k] = ET<T>::to_f(ET<T>::from_f(fmaxf(z[k], 0.f)));
+        }
+        const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        const bool e0 = a[0] == m, e1 = a[1] == m, e2 = a[2] == m;
+        const bool f[4] = {e0, !e0 && e1, !(e0 || e1) && e2, !(e0 || e1 || e2)};   // the FIRST maximum takes the gradient
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = f[k] ? od[k][j] + gr[j] : od[k][j];
+          const float da = ET<T>::to_f(ET<T>::from_f(d));
+          const float v = z[k] > 0.f ? da : 0.f;
+          od[k][j] = v;
+          s0[j] += v;
+          s1[j] = fmaf(v, yv[k][j] - mu[j], s1[j]);
+        }
+      }
+      Vec<T>::store(dz + base, od[0]);
+      Vec<T>::store(dz + o1, od[1]);
+      Vec<T>::store(dz + o2, od[2]);
+      Vec<T>::store(dz + o3, od[3]);
+    } else {
     float yv[4][PIECE], av[4][PIECE], gr[PIECE];
     bool on[4][PIECE];
 #pragma unroll
@@ -408,6 +462,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
       }
       Vec<T>::store(dz + o, d);
     }
+    }
+    // next window of this thread
+    ox += sx;
+    if (ox >= WW) { ox -= WW; ++oy; }
+    oy += sy;
+    if (oy >= WH) { oy -= WH; ++n; }
+    n += sn;
   }
   // block partial: the 256 / G threads of a channel group, in thread order
 #pragma unroll

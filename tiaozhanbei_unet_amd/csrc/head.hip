@@ -76,6 +76,38 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
           for (int j = 0; j < PIECE; ++j)
             v[i][j] = ET<T>::to_f(ET<T>::from_f(fmaxf(fmaf(v[i][j], sc[j], sh[j]), 0.f)));
       }
+      if constexpr (TPP == 8) {
+        // 64 input channels in bf16 (the benchmark's heads): the 8 lanes of a pixel group hold 8 sub-steps x CO partial
+        // dot products.  A reduce-scatter over the lane bits (7 exchanges per filter instead of 24 butterfly steps + 8
+        // gathers) leaves lane g with the finished sum of sub-step g -- the same pairwise tree as the butterfly, bit for
+        // bit -- and the wave's 64 results are its 64 consecutive pixels in a permuted lane order: the NCHW planes are
+        // still written as 256 contiguous bytes.
+        static_assert(SB == 8 && S == 8, "one batch");
+        const bool b0 = g & 1, b1 = g & 2, b2 = g & 4;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          float a[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < PIECE; ++j) a[i] = fmaf(v[i][j], wr[co][j], a[i]);
+          }
+          float h4[4], h2[2];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float keep = b0 ? a[2 * k + 1] : a[2 * k], send = b0 ? a[2 * k] : a[2 * k + 1];
+            h4[k] = keep + __shfl_xor(send, 1);
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float keep = b1 ? h4[2 * k + 1] : h4[2 * k], send = b1 ? h4[2 * k] : h4[2 * k + 1];
+            h2[k] = keep + __shfl_xor(send, 2);
+          }
+          const float keep = b2 ? h2[1] : h2[0], send = b2 ? h2[0] : h2[1];
+          res[co] = keep + __shfl_xor(send, 4);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < SB; ++i) {
         const int s = s0 + i;
@@ -97,8 +129,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
           if (lane / PPW == s) res[co] = t;
         }
       }
+      }
     }
-    const long long p = base + lane;
+    const long long p = base + (TPP == 8 ? g * PPW + sub : lane);
     if (p < pixels) {
       long long n, q;
       split_pixel(p, hw, n, q);

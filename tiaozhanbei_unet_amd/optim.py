@@ -32,7 +32,9 @@ class FusedAdam(torch.optim.Optimizer):
         the update rule is taken from torch's key and every ``step`` goes back to a host fp32 scalar (reading a device
         scalar would be one host sync per parameter per step)."""
         for group in self.param_groups:
-            group.setdefault("decoupled", bool(group.get("decoupled_weight_decay", False)))
+            # torch < 2.7 wrote AdamW checkpoints without ``decoupled_weight_decay``: then the rule this optimiser was
+            # constructed with (get_optimizer's --optimizer choice) stands
+            group.setdefault("decoupled", bool(group.get("decoupled_weight_decay", self.defaults.get("decoupled", False))))
         for st in self.state.values():
             if "step" in st:
                 v = st["step"]
