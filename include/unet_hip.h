@@ -377,6 +377,54 @@ int32_t unet_anomaly_score(const float* recon, const float* image, int32_t n, in
 int32_t unet_preprocess_u8(const uint8_t* images_hwc, const uint8_t* flip, float* out_nchw, int32_t n, int32_t h,
                            int32_t w, const float* mean3, const float* std3, void* stream);
 
+/* ---- the rest of the loaders' image transform on the GPU (round 4).  The reference runs torchvision on
+ * PIL images (src/dataset.py:134-141: Resize -> RandomHorizontalFlip -> RandomRotation(10) -> ColorJitter(0.1, 0.1,
+ * 0.1, 0.05) -> ToTensor -> Normalize; src/kolektorsdd_dataset.py:133-150: the same with RandomRotation(5), masks
+ * Resize(NEAREST)); each entry point below restates the arithmetic of the Pillow C kernel that transform ends in and is
+ * bit-exact against fixtures produced by PIL (tests/golden/aug_*.npz).  Batches are decoded uint8 images [n][h][w][c]
+ * in device memory; the random draws stay with the host and come in as per-image parameters.
+ *
+ * transforms.Resize on a PIL image = Image.resize(BILINEAR) = ImagingResample (Resample.c): a separable triangle filter
+ * whose support grows with the down-scale factor, 22-bit fixed-point coefficients, 8-bit intermediate image between the
+ * horizontal and the vertical pass.  unet_resize_bilinear_coeffs (HOST function, host arrays) writes PIL's tables for
+ * one axis: bounds[out][2] = (first source index, count), kk[out][ksize] with ksize = unet_resize_bilinear_ksize(..).
+ * unet_resize_bilinear_u8 takes those tables in DEVICE memory (x tables for w -> out_w, y tables for h -> out_h; a pass
+ * whose size does not change is skipped like PIL skips it and its tables may be NULL), tmp = [n][h][out_w][c] bytes
+ * (needed when both passes run), c = 1 or 3. */
+int32_t unet_resize_bilinear_ksize(int32_t in_size, int32_t out_size);
+int32_t unet_resize_bilinear_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk);
+int32_t unet_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t c, int32_t out_h,
+                                int32_t out_w, const int32_t* xbounds, const int32_t* xkk, int32_t xksize,
+                                const int32_t* ybounds, const int32_t* ykk, int32_t yksize, uint8_t* tmp, uint8_t* dst,
+                                void* stream);
+/* Image.resize(NEAREST) (Geometry.c ImagingScaleAffine; the mask transform of src/kolektorsdd_dataset.py:147-150 and
+ * :116-117): unet_resize_nearest_index (HOST) writes the source index of every output position of one axis (-1 =
+ * outside); unet_resize_nearest_u8 gathers with the y / x tables in DEVICE memory. */
+int32_t unet_resize_nearest_index(int32_t in_size, int32_t out_size, int32_t* idx);
+int32_t unet_resize_nearest_u8(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t c, int32_t out_h,
+                               int32_t out_w, const int32_t* yidx, const int32_t* xidx, uint8_t* dst, void* stream);
+/* RandomHorizontalFlip + RandomRotation: dst = rotate(flip[n] ? mirror(src) : src) with Image.rotate(angle, NEAREST,
+ * expand=False, fill 0) = Geometry.c affine_fixed in 16.16 fixed point.  matrices[n][6] (DEVICE, may be NULL: no
+ * rotation) = {a0, a1, a2, a3, a4, a5} ALREADY in fixed point, a2 / a5 including the half-pixel terms (FIX(a[2] +
+ * a[0]*0.5 + a[1]*0.5)); flip[n] DEVICE bytes, may be NULL.  src != dst; sides < 32768; c <= 4. */
+int32_t unet_flip_rotate_u8(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t c, const uint8_t* flip,
+                            const int32_t* matrices, uint8_t* dst, void* stream);
+/* ColorJitter + ToTensor + Normalize of RGB batches.  Per image: `order` = the permutation torchvision draws (entries:
+ * 0 brightness, 1 contrast, 2 saturation, 3 hue, -1 = skip), the three ImageEnhance factors (Blend.c: float32, truncating)
+ * and hue_shift = uint8(hue_factor * 255) added to H of Convert.c's integer HSV.  The contrast operation needs the mean
+ * L of the image as it is at that point of the list: one integer-sum pass, then one pass that applies the list and
+ * writes out[n][c][y][x] = (u8 / 255 - mean[c]) / std[c] (fp32 NCHW, as unet_preprocess_u8).  desc: DEVICE array of n
+ * (NULL: no jitter, no workspace needed); mean3 / std3: HOST arrays. */
+typedef struct unet_jitter_desc {
+  int32_t order[4];
+  float brightness, contrast, saturation;
+  int32_t hue_shift;
+} unet_jitter_desc;
+size_t unet_color_jitter_workspace(int32_t n);
+int32_t unet_color_jitter_normalize_u8(const uint8_t* images_hwc, int32_t n, int32_t h, int32_t w,
+                                       const unet_jitter_desc* desc, const float* mean3, const float* std3,
+                                       float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One fused step over a flat fp32 parameter arena: L2-coupled weight decay, bias correction,
  * gradient pre-scale (1/world_size under data parallelism). step is 1-based.  The betas are doubles so that 1 - beta is
  * formed in double before rounding to fp32, as torch.optim.Adam's `value=1 - beta2` is. */

@@ -104,21 +104,26 @@ def test_mvtec_reader_contract(tmp_path):
         labels += b["label"].tolist(); mx = max(mx, float(b["mask"].max()))
     assert sorted(labels) == [0, 0, 1, 1]
     assert 0 < mx <= 1.0 / 255.0 + 1e-9, "masks are {0,1} uint8 scaled by 1/255 (reference quirk)"
-    # device_preprocess form (what the GPU box uses): the same samples as uint8 HWC + flip flag; host normalisation of
-    # those bytes reproduces the float form exactly (the device does that arithmetic in unet_preprocess_u8)
-    import random
-    import numpy as np
+    # device_preprocess form (what train.py / test.py select): workers only decode -- samples carry the raw uint8 image
+    # and {0, 1} mask at their native size; collate_raw stacks equal sizes and keeps ragged ones as a list
     from tiaozhanbei_unet_amd import dataset as D
     for split, is_train in (("train", True), ("test", False)):
-        random.seed(5)
-        host = [D.MVTecDataset(root, "bottle", split, 32, is_train, device_preprocess=False)[i] for i in range(2)]
-        random.seed(5)
-        dev_ = [D.MVTecDataset(root, "bottle", split, 32, is_train, device_preprocess=True)[i] for i in range(2)]
-        for h, d in zip(host, dev_):
-            assert set(d) == {"image_u8", "flip", "mask", "label", "anomaly_type", "image_path"}
-            assert d["image_u8"].dtype == torch.uint8 and tuple(d["image_u8"].shape) == (32, 32, 3)
-            assert torch.equal(D._normalise(d["image_u8"].numpy(), bool(d["flip"])), h["image"])
-            assert torch.equal(d["mask"], h["mask"])
+        ds = D.MVTecDataset(root, "bottle", split, 32, is_train, device_preprocess=True)
+        assert ds.device_transform is not None and ds.device_transform.train == (split == "train")
+        d = ds[len(ds) - 1]
+        assert set(d) == {"image_raw", "mask_raw", "label", "anomaly_type", "image_path"}
+        assert d["image_raw"].dtype == torch.uint8 and tuple(d["image_raw"].shape) == (40, 40, 3)
+        assert d["mask_raw"].dtype == torch.uint8 and tuple(d["mask_raw"].shape) == (40, 40, 1)
+        assert int(d["mask_raw"].max()) == (1 if split == "test" else 0)
+        b = D.collate_raw([ds[0], ds[1]])
+        assert tuple(b["image_raw"].shape) == (2, 40, 40, 3) and b["label"].tolist() == [ds[0]["label"], ds[1]["label"]]
+        ragged = dict(ds[0]); ragged["image_raw"] = ragged["image_raw"][:30]
+        assert isinstance(D.collate_raw([ragged, ds[1]])["image_raw"], list)
+    # the host transform draws flip / rotation / colour jitter for the training split only
+    ev = D.MVTecDataset(root, "bottle", "test", 32, False)
+    assert torch.equal(ev[0]["image"], ev[0]["image"])
+    tr = D.MVTecDataset(root, "bottle", "train", 32, True)
+    assert not torch.equal(tr[0]["image"], tr[0]["image"])
 
 
 def test_shard_sampler_gives_disjoint_equal_shards():
@@ -147,8 +152,8 @@ def test_kolektorsdd_reader_contract(tmp_path):
     """kolektorsdd_dataset.KolektorSDDDataset against the reference's rules (src/kolektorsdd_dataset.py:47-126):
     sorted discovery of kos*/X.jpg + X_label.bmp pairs, 70/15/15 split sizes from the sorted list then the seed-42
     shuffle (identical to `random.seed(42); random.shuffle(...)`), masks clamped to {0,1,2} and resized NEAREST,
-    (image, mask, path) samples, 3 classes.  (torchvision is not importable here: parity with the reference's
-    transforms is pinned by rule, not by fixture -- "parity unpinned" for the PIL resize.)"""
+    (image, mask, path) samples, 3 classes.  (torchvision is not importable here; on PIL images it delegates the resize
+    to Pillow, which the host path calls and the oracle restates -- tests/test_oracle_aug_golden.py pins that.)"""
     import random
     import numpy as np
     import torch
@@ -165,11 +170,17 @@ def test_kolektorsdd_reader_contract(tmp_path):
     img, mask, path = ds[0]
     assert img.shape == (3, 96, 32) and img.dtype == torch.float32 and mask.shape == (96, 32) and mask.dtype == torch.int64
     assert int(mask.max()) <= 2 and int(mask.min()) >= 0 and os.path.exists(path) and ds.num_classes == 3
+    # raw samples (for GpuPreprocess): the decoded image / clamped mask at their NATIVE size; the host sample is Pillow's
+    # resize of exactly those bytes (pinned against the oracle's restatement of Pillow's resampling arithmetic)
+    from oracle import pil_oracle as PO
     raw = K.KolektorSDDDataset(root, "train", image_size=(96, 32), raw=True)
     u8, mask2, _ = raw[0]
-    assert u8.dtype == torch.uint8 and u8.shape == (96, 32, 3) and torch.equal(mask, mask2)
-    want = (u8.float().permute(2, 0, 1) / 255.0 - torch.tensor(K.MEAN)) / torch.tensor(K.STD)
+    assert u8.dtype == torch.uint8 and u8.shape == (160, 64, 3) and mask2.shape == (160, 64, 1) and int(mask2.max()) <= 2
+    want = torch.from_numpy(PO.to_tensor_normalize(PO.resize_bilinear(u8.numpy(), 96, 32)))
     assert torch.equal(img, want)
+    assert torch.equal(mask, torch.from_numpy(PO.resize_nearest(mask2.numpy(), 96, 32)[..., 0]).long())
+    xs, ms, ps = K.collate_raw([raw[0], raw[1]])
+    assert tuple(xs.shape) == (2, 160, 64, 3) and tuple(ms.shape) == (2, 160, 64, 1) and len(ps) == 2
     tr, va, te, ncls = K.get_kolektorsdd_dataloaders(root, batch_size=4, image_size=(96, 32), num_workers=0)
     assert ncls == 3 and len(tr.dataset) == 14 and len(va.dataset) == 3 and len(te.dataset) == 3
     xb, mb, pb = next(iter(va))

@@ -190,28 +190,40 @@ print("RCCL_OK")
 
 
 def test_mvtec_loader_preprocesses_on_the_device_bit_identically(tmp_path):
-    """the MVTec loaders built on a GPU box ship uint8 HWC images + flip flags; train_utils._batches turns
-    a batch into normalised fp32 NCHW with ONE unet_preprocess_u8 launch -- bit-identical to the host arithmetic of
-    src/dataset.py:134-146 (ToTensor, Normalize) on the same bytes, flips included."""
-    import random
+    """loaders built with ``device_preprocess`` ship the decoded uint8 images / masks; train_utils._batches
+    runs the WHOLE transform of src/dataset.py:134-151 on the GPU (round 4: resize, flip, rotation, colour jitter too).
+    Eval split: bit-identical to the host loader (Pillow on the same files).  Train split: bit-identical to the oracle's
+    restatement of Pillow's arithmetic replayed with the parameters the device transform drew."""
+    import numpy as np
+    from oracle import pil_oracle as PO
     from tiaozhanbei_unet_amd import dataset as D, train_utils as T
     root = D.write_synthetic_mvtec(str(tmp_path), "bottle", n_train=6, n_good=2, n_bad=2, size=48)
-    tr_dev, te_dev = D.get_dataloaders(root, "bottle", batch_size=3, image_size=40, num_workers=0)       # default on a GPU box
+    tr_dev, te_dev = D.get_dataloaders(root, "bottle", batch_size=3, image_size=40, num_workers=0, device_preprocess=True)
     assert tr_dev.dataset.device_preprocess and te_dev.dataset.device_preprocess
-    for split, is_train in (("train", True), ("test", False)):
-        host = D.MVTecDataset(root, "bottle", split, 40, is_train, device_preprocess=False)
-        dev_ = D.MVTecDataset(root, "bottle", split, 40, is_train, device_preprocess=True)
-        random.seed(11)
-        hb = [host[i] for i in range(len(host))]
-        random.seed(11)
-        loader = torch.utils.data.DataLoader(dev_, batch_size=len(dev_), shuffle=False, num_workers=0)
-        (batch, images, masks), = list(T._batches(loader, DEV))
-        assert images.shape == (len(host), 3, 40, 40) and images.dtype == torch.float32 and images.is_cuda
-        want = torch.stack([b["image"] for b in hb])
-        assert torch.equal(images.cpu(), want), float((images.cpu() - want).abs().max())
-        assert torch.equal(masks.cpu(), torch.stack([b["mask"] for b in hb]))
-        if is_train:
-            assert 0 < int(batch["flip"].sum()) < len(host), "seed 11 draws both flipped and unflipped samples"
+    host = D.MVTecDataset(root, "bottle", "test", 40, False)
+    seen = 0
+    for batch, images, masks in T._batches(te_dev, DEV):
+        assert set(batch) == {"image", "mask", "label", "anomaly_type", "image_path"} and images.is_cuda
+        for j in range(images.shape[0]):
+            h = host[seen + j]
+            assert torch.equal(images[j].cpu(), h["image"]) and torch.equal(masks[j].cpu(), h["mask"])
+        seen += images.shape[0]
+    assert seen == len(host) == 4
+    ds = tr_dev.dataset
+    raw = [ds[i] for i in range(len(ds))]
+    tf = ds.device_transform
+    tf.gen.manual_seed(11)
+    p = tf.draw(len(raw))
+    got = tf([r["image_raw"] for r in raw], p, device=DEV).cpu().numpy()
+    assert 0 < sum(p["flips"]) < len(raw), "seed 11 draws both flipped and unflipped samples"
+    for i, r in enumerate(raw):
+        want = PO.train_transform(r["image_raw"].numpy(), 40, 40, p["flips"][i], p["angles"][i], p["orders"][i],
+                                  p["brightness"][i], p["contrast"][i], p["saturation"][i], p["hue"][i])
+        assert np.array_equal(got[i], want), i
+    # and through the loop helper: shapes / dtypes / keys of a training batch
+    (batch, images, masks), *_ = list(T._batches(tr_dev, DEV))
+    assert images.shape == (3, 3, 40, 40) and images.dtype == torch.float32 and masks.shape == (3, 1, 40, 40)
+    assert float(masks.max()) == 0.0
 
 
 def test_threshold_confusion_matches_the_host_epilogue():

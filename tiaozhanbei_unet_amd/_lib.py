@@ -103,6 +103,14 @@ SIGNATURES = {
     "unet_anomaly_score_workspace": (_z, [_i, _l]),
     "unet_anomaly_score": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p, _z, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "unet_resize_bilinear_ksize": (_i, [_i, _i]),
+    "unet_resize_bilinear_coeffs": (_i, [_i, _i, _p, _p]),
+    "unet_resize_bilinear_u8": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "unet_resize_nearest_index": (_i, [_i, _i, _p]),
+    "unet_resize_nearest_u8": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "unet_flip_rotate_u8": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "unet_color_jitter_workspace": (_z, [_i]),
+    "unet_color_jitter_normalize_u8": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _z, _p]),
     "unet_adam_chunk_elems": (_i, []),
     "unet_adam_multi": (_i, [_p, _p, _i, _f, _d, _d, _f, _f, _f, _i, _i, _p]),
     "unet_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _d, _d, _f, _f, _f, _i, _p]),

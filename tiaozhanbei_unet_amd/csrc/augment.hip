@@ -17,6 +17,9 @@
 
 #include "common.h"
 
+// no fused multiply-adds anywhere in this file, host or device: PIL's arithmetic rounds every product and every sum
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;      // Resample.c
@@ -254,11 +257,8 @@ extern "C" int32_t unet_resize_bilinear_ksize(int32_t in_size, int32_t out_size)
 }
 
 // Resample.c precompute_coeffs (bilinear: support 1, filter 1 - |x|) + normalize_coeffs_8bpc, in host doubles.
-// (-ffp-contract=off for this function's arithmetic: every product and sum rounds once, as in PIL's build)
-#pragma clang fp contract(off)
 extern "C" int32_t unet_resize_bilinear_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk) {
   UNET_REQUIRE(in_size > 0 && out_size > 0 && bounds && kk, UNET_ERR_BAD_ARG, "unet_resize_bilinear_coeffs: bad argument");
-#pragma clang fp contract(off)
   const double scale = (double)in_size / (double)out_size;
   double filterscale = scale;
   if (filterscale < 1.0) filterscale = 1.0;
@@ -274,7 +274,6 @@ extern "C" int32_t unet_resize_bilinear_coeffs(int32_t in_size, int32_t out_size
     if (xmax > in_size) xmax = in_size;
     xmax -= xmin;
     double k[64];
-    UNET_REQUIRE(ksize <= 64 || true, UNET_ERR_UNSUPPORTED, "ksize");
     double* kd = k;
     double* big = nullptr;
     if (ksize > 64) { big = new double[ksize]; kd = big; }
@@ -303,7 +302,6 @@ extern "C" int32_t unet_resize_bilinear_coeffs(int32_t in_size, int32_t out_size
 // position -- the accumulated double, not a product -- and COORD(xo) = (int)xo for xo >= 0
 extern "C" int32_t unet_resize_nearest_index(int32_t in_size, int32_t out_size, int32_t* idx) {
   UNET_REQUIRE(in_size > 0 && out_size > 0 && idx, UNET_ERR_BAD_ARG, "unet_resize_nearest_index: bad argument");
-#pragma clang fp contract(off)
   const double a0 = (double)in_size / (double)out_size;
   double xo = 0.0 + a0 * 0.5;
   for (int x = 0; x < out_size; ++x) {

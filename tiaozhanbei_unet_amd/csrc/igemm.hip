@@ -2616,8 +2616,7 @@ int32_t launch_ws(IgemmParams P, int kclass, hipStream_t s, int* stat_parts) {
   // MFMA phase); UNET_WS_ST=0 / 1 force lock-step / staggered, 3 = staggered for the BatchNorm-backward form too
   const char stv = unet_tuning().ws_st;
   // default: the 16x16x32 kernel (conv3_ws16_kernel); UNET_WS_MFMA=3 selects the 32x32x16 one (and its staggered forms)
-  // (the BatchNorm-backward form spills 9 registers in its epilogue on the new kernel and is still faster end to end:
-  //  18.87 -> 18.71 ms per step)
+  // (every form of it is spill-free -- tools/check_dpp_hazards.py asserts that; 18.87 -> 18.71 ms per step when it came in)
   P.ws_stagger = unet_tuning().ws_stg == '0' ? 0 : (unet_tuning().ws_stg == '1' ? 1 : 2);
   const bool old32 = unet_tuning().ws_mfma == '3';
   bool dense16 = P.H % 16 == 0 && P.W % 16 == 0;

@@ -3,9 +3,10 @@
 Same sample discovery (`kos*/PartN.jpg` + `PartN_label.bmp`, :55-68), the same deterministic 70/15/15 split (sorted
 list, `random.seed(42)` shuffle, :70-90), masks clamped to {0,1,2} (:108-111) and resized with NEAREST (:121-124),
 `(image, mask, img_path)` samples (:126) and `get_kolektorsdd_dataloaders(...) -> (train, val, test, num_classes)`
-(:157-223).  torchvision is absent from this environment: the image resize is PIL bilinear (what torchvision's
-Resize calls on PIL images); normalisation and the horizontal flip can run on the GPU (`GpuPreprocess`, libunet_hip's
-unet_preprocess_u8) so the loader workers only decode and resize.  ColorJitter / RandomRotation are not reproduced.
+(:157-223).  torchvision is absent from this environment: the host path resizes with PIL (what torchvision's Resize
+calls on PIL images) and normalises; with ``raw=True`` the workers only DECODE and `GpuPreprocess` runs the whole
+transform of :133-155 on the GPU (augment.py / csrc/augment.hip, bit-exact to Pillow): bilinear resize, horizontal flip,
+RandomRotation(5), ColorJitter(0.1, 0.1, 0.1, 0.05), ToTensor, Normalize, and the NEAREST mask resize.
 With ``world > 1`` the train loader draws from this rank's ``dataset.ShardSampler`` shard."""
 from __future__ import annotations
 
@@ -57,8 +58,9 @@ def split_samples(samples, split, train_split=0.7, val_split=0.15):
 
 
 class KolektorSDDDataset(Dataset):
-    """``raw=True``: images stay uint8 HWC (decode + resize only) for ``GpuPreprocess``; otherwise normalised CHW fp32
-    tensors like the reference's eval transform (ToTensor + Normalize, :146-150)."""
+    """``raw=True``: samples are the DECODED uint8 image [H, W, 3] and clamped mask [H, W, 1] at their native size (the
+    parts differ: ~1240-1270 x 500) for ``GpuPreprocess``; otherwise normalised CHW fp32 tensors and resized long masks
+    like the reference's eval transform (Resize + ToTensor + Normalize, :146-155)."""
 
     def __init__(self, root_dir, split="train", image_size=(1024, 512), train_split=0.7, val_split=0.15, raw=False):
         self.root_dir, self.split, self.image_size, self.raw = root_dir, split, tuple(image_size), raw
@@ -72,42 +74,55 @@ class KolektorSDDDataset(Dataset):
 
     def __getitem__(self, idx):
         h, w = self.image_size
-        img = Image.open(self.image_paths[idx]).convert("RGB").resize((w, h), Image.BILINEAR)
+        img = Image.open(self.image_paths[idx]).convert("RGB")
         mask = np.clip(np.array(Image.open(self.mask_paths[idx]).convert("L")), 0, 2).astype(np.uint8)
+        if self.raw:
+            return torch.from_numpy(np.array(img, dtype=np.uint8)), torch.from_numpy(mask[:, :, None].copy()), self.image_paths[idx]
+        img = img.resize((w, h), Image.BILINEAR)
         mask = Image.fromarray(mask, mode="L").resize((w, h), Image.NEAREST)
         mask = torch.from_numpy(np.array(mask)).long()
-        a = np.asarray(img, dtype=np.uint8)
-        if self.raw:
-            return torch.from_numpy(a.copy()), mask, self.image_paths[idx]
-        a = a.astype(np.float32).transpose(2, 0, 1) / 255.0
+        a = np.array(img, dtype=np.uint8).astype(np.float32).transpose(2, 0, 1) / 255.0
         return torch.from_numpy((a - MEAN) / STD), mask, self.image_paths[idx]
 
 
-class GpuPreprocess:
-    """ToTensor + Normalize(ImageNet) (+ RandomHorizontalFlip(p) of image AND mask for training) on the GPU
-    (reference :133-150 / src/dataset.py:130-146) for batches of uint8 HWC images: one unet_preprocess_u8 launch."""
+def collate_raw(samples):
+    """(images, masks, paths) of ``raw`` samples: stacked when the parts have one size, lists otherwise."""
+    imgs, masks, paths = zip(*samples)
+    same = len({tuple(t.shape) for t in imgs}) == 1
+    return (torch.stack(imgs) if same else list(imgs)), (torch.stack(masks) if same else list(masks)), list(paths)
 
-    def __init__(self, train=False, flip_p=0.5, seed=0):
-        self.train, self.flip_p = train, flip_p
-        self.gen = torch.Generator().manual_seed(seed)
+
+class GpuPreprocess:
+    """get_kolektorsdd_transforms (reference :133-155) on the GPU for batches of ``raw`` samples: images Resize (bilinear)
+    [-> RandomHorizontalFlip -> RandomRotation(5) -> ColorJitter when ``train``] -> ToTensor -> Normalize; masks Resize
+    (NEAREST) -> long.  The reference applies the random flip / rotation to the image ONLY (its target_transform has
+    none, :151-155), which misaligns image and mask; ``sync_mask=True`` (default) applies the same flip and rotation
+    (nearest, fill 0 = background) to the mask, ``sync_mask=False`` reproduces the reference."""
+
+    def __init__(self, image_size=(1024, 512), train=False, flip_p=0.5, degrees=5.0, seed=0, sync_mask=True):
+        from .augment import DeviceTransform
+        self.train, self.sync_mask = bool(train), bool(sync_mask)
+        self.tf = DeviceTransform(tuple(image_size), train=train, degrees=degrees, flip_p=flip_p, seed=seed)
 
     def __call__(self, images_u8, masks=None, device="cuda"):
-        from . import ops
-        n = images_u8.shape[0]
-        flips = (torch.rand(n, generator=self.gen) < self.flip_p) if self.train else torch.zeros(n, dtype=torch.bool)
-        x = ops.preprocess_u8(images_u8.to(device, non_blocking=True), flips.to(device))
+        from . import augment as A
+        n = len(images_u8)
+        params = self.tf.draw(n) if self.train else None
+        x = self.tf(images_u8, params, device=device)
         if masks is None:
             return x
-        masks = masks.to(device, non_blocking=True)
-        if self.train and bool(flips.any()):
-            masks = torch.where(flips.to(device)[:, None, None], masks.flip(-1), masks)
-        return x, masks
+        m = A._resize_any(masks, self.tf.size[0], self.tf.size[1], x.device, nearest=True)
+        if self.train and self.sync_mask:
+            m = A.flip_rotate_u8(m, params["flips"], params["angles"])
+        return x, m[..., 0].long()
 
 
 def get_kolektorsdd_dataloaders(root_dir, batch_size=16, image_size=(1024, 512), num_workers=4, train_split=0.7,
                                 val_split=0.15, rank=0, world=1, seed=0, raw=False):
     sets = [KolektorSDDDataset(root_dir, s, image_size, train_split, val_split, raw) for s in ("train", "val", "test")]
     kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=torch.cuda.is_available())
+    if raw:
+        kw["collate_fn"] = collate_raw
     if world > 1:
         train = DataLoader(sets[0], sampler=ShardSampler(len(sets[0]), rank, world, True, seed), **kw)
     else:

@@ -381,21 +381,10 @@ class AnomalyUNet(_HipBlock):
         with _BatchedCounters():
             return self._forward(x)
 
-    _warned_off = False
-
     def _forward(self, x):
         ops._require_cuda(x)
         _pack_cache(self)
         feats = _encoder(self, x)
-        if self.two_streams and torch.is_grad_enabled() and not AnomalyUNet._warned_off:
-            # The segmentation decoder's weight gradients are produced on the side stream, their AccumulateGrad nodes
-            # belong to the stream the parameters live on: autograd orders the two with an event wait -- exactly the
-            # dependency the optimiser step needs -- and warns about it once per process.  The wait is wanted; the
-            # warning is not.
-            setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if setter is not None:
-                setter(False)
-            AnomalyUNet._warned_off = True
         if not self.two_streams:
             return self._decode(feats, "recon"), self._decode(feats, "seg")
         main = torch.cuda.current_stream(x.device)
@@ -406,4 +395,27 @@ class AnomalyUNet(_HipBlock):
         reconstruction = self._decode(feats, "recon")
         main.wait_stream(side)
         anomaly_map.record_stream(main)
+        if torch.is_grad_enabled() and (reconstruction.requires_grad or anomaly_map.requires_grad):
+            reconstruction, anomaly_map = _QuietStreamMismatch.apply(reconstruction, anomaly_map)
         return reconstruction, anomaly_map
+
+
+class _QuietStreamMismatch(torch.autograd.Function):
+    """Identity on the two outputs of a two-stream AnomalyUNet forward.  The segmentation decoder's weight gradients are
+    produced on the side stream while their AccumulateGrad nodes belong to the stream the parameters live on: autograd
+    orders the two with an event wait -- exactly the dependency the optimiser step needs -- and warns about it.  The
+    wait is wanted, the warning is not: this node runs FIRST in the backward pass, switches the warning off and queues an
+    engine callback that switches it back on when THIS backward pass has finished -- the process-wide setting is
+    untouched outside the model's own backward (``UNET_KEEP_STREAM_WARNING=1`` leaves it alone altogether)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if setter is not None and os.environ.get("UNET_KEEP_STREAM_WARNING", "0") == "0":
+            setter(False)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: setter(True))
+        return ga, gb

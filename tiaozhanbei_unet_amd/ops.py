@@ -995,14 +995,18 @@ def threshold_confusion(pred, truth, thresholds, select=None, counts=None):
         raise ValueError("threshold_confusion: prediction / truth shapes differ")
     n = p.shape[0]
     per = p.numel() // n
-    thr = torch.tensor([float(v) for v in thresholds], dtype=torch.float32, device=p.device)
-    if not 1 <= thr.numel() <= 8:
-        raise ValueError("threshold_confusion: 1..8 thresholds")
+    values = [float(v) for v in thresholds]
+    if not values:
+        raise ValueError("threshold_confusion: at least one threshold")
     sel = None if select is None else torch.as_tensor(select).to(device=p.device, dtype=torch.uint8).contiguous()
     if counts is None:
-        counts = torch.zeros((thr.numel(), 4), dtype=torch.int64, device=p.device)
-    L.check(L.lib().unet_threshold_confusion(_ptr(p), _ptr(t), _ptr(sel), n, per, _ptr(thr), thr.numel(), _ptr(counts),
-                                             _stream()), "unet_threshold_confusion")
+        counts = torch.zeros((len(values), 4), dtype=torch.int64, device=p.device)
+    if tuple(counts.shape) != (len(values), 4):
+        raise ValueError("threshold_confusion: counts must be [len(thresholds), 4]")
+    for k in range(0, len(values), 8):           # the kernel takes up to 8 thresholds per pass over the maps
+        thr = torch.tensor(values[k:k + 8], dtype=torch.float32, device=p.device)
+        L.check(L.lib().unet_threshold_confusion(_ptr(p), _ptr(t), _ptr(sel), n, per, _ptr(thr), thr.numel(),
+                                                 _ptr(counts[k:k + 8]), _stream()), "unet_threshold_confusion")
     return counts
 
 

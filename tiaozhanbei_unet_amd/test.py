@@ -44,7 +44,7 @@ def test_model(model, test_loader, device, threshold=None, pixel_thresholds=None
     pix = None
     with torch.no_grad():
         from .train_utils import _batches
-        for batch, images, _ in _batches(test_loader, device):     # (uint8 batches are normalised on the device)
+        for batch, images, _ in _batches(test_loader, device):     # (raw uint8 batches are transformed on the device)
             if isinstance(model, AnomalyUNet):
                 recon, amap = model(images)
             else:
@@ -54,7 +54,7 @@ def test_model(model, test_loader, device, threshold=None, pixel_thresholds=None
                                               select=torch.as_tensor(np.asarray(batch["label"]) == 1), counts=pix)
             out["anomaly_scores"].extend(compute_anomaly_score(recon, images).cpu().numpy())
             out["images"].extend(images.cpu()); out["reconstructions"].extend(recon.cpu())
-            out["anomaly_maps"].extend(amap.cpu().numpy()); out["masks_true"].extend(batch["mask"].numpy())
+            out["anomaly_maps"].extend(amap.cpu().numpy()); out["masks_true"].extend(batch["mask"].cpu().numpy())
             out["labels"].extend(np.asarray(batch["label"])); out["anomaly_types"].extend(batch["anomaly_type"])
             out["image_paths"].extend(batch["image_path"])
     for k in ("labels", "anomaly_scores", "masks_true", "anomaly_maps"):
@@ -109,7 +109,8 @@ def main(argv=None):
         return
     out_dir = os.path.join(args.output_dir, f"{args.category}_test_results")
     os.makedirs(out_dir, exist_ok=True)
-    _, loader = get_dataloaders(args.data_root, args.category, args.batch_size, args.image_size, args.num_workers)
+    _, loader = get_dataloaders(args.data_root, args.category, args.batch_size, args.image_size, args.num_workers,
+                                device_preprocess=True)                     # workers decode, the GPU transforms
     model = (AnomalyUNet(3, args.bilinear, precision=args.precision) if args.model == "anomaly_unet"
              else UNet(3, 1, args.bilinear, precision=args.precision)).to(device)
     load_checkpoint(model, None, args.checkpoint, device)

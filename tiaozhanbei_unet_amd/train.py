@@ -110,7 +110,8 @@ def main(argv=None):
     # data parallel: every rank trains on its own shard (dataset.ShardSampler: same permutation on every rank, strided
     # shards padded to equal length), validation runs on rank 0 over the whole test split
     train_loader, val_loader = get_dataloaders(args.data_root, args.category, args.batch_size, args.image_size,
-                                               args.num_workers, rank=rank, world=world, seed=args.seed)
+                                               args.num_workers, rank=rank, world=world, seed=args.seed,
+                                               device_preprocess=True)      # workers decode, the GPU transforms
     if args.debug:
         import random
         from torch.utils.data import DataLoader, Subset
@@ -119,7 +120,8 @@ def main(argv=None):
         def limit(loader, train):
             idx = picker.sample(range(len(loader.dataset)), min(args.debug_samples, len(loader.dataset)))
             sub = Subset(loader.dataset, idx)
-            kw = dict(batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=True)
+            kw = dict(batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=True,
+                      collate_fn=loader.collate_fn)
             if train and world > 1:
                 return DataLoader(sub, sampler=ShardSampler(len(sub), rank, world, True, args.seed), **kw)
             return DataLoader(sub, shuffle=train, **kw)

@@ -64,15 +64,23 @@ PIXEL_THRESHOLDS = (0.3, 0.5, 0.7)          # src/train_utils.py:234
 
 
 def _batches(loader, device):
-    """(batch dict, images, masks) on the device.  Loaders built with ``device_preprocess`` ship uint8 HWC images and
-    flip flags: flip + ToTensor + Normalize (src/dataset.py:134-146) are one unet_preprocess_u8 launch per batch."""
+    """(batch dict, images, masks) on the device.  Loaders built with ``device_preprocess`` ship the decoded uint8
+    images / masks: the whole image transform of src/dataset.py:134-151 (resize, flip, rotation, colour jitter, ToTensor,
+    Normalize) then runs on the GPU (augment.DeviceTransform of the loader's dataset) and the batch regains the
+    reference's ``image`` / ``mask`` keys."""
+    ds, tf = getattr(loader, "dataset", None), None
+    while ds is not None and tf is None:            # (a torch Subset wraps the dataset that owns the transform)
+        tf, ds = getattr(ds, "device_transform", None), getattr(ds, "dataset", None)
     for batch in loader:
-        if "image_u8" in batch:
-            images = ops.preprocess_u8(batch["image_u8"].to(device, non_blocking=True), batch["flip"])
-            batch["image"] = images
-        else:
-            images = batch["image"].to(device, non_blocking=True)
-        yield batch, images, batch["mask"].to(device, non_blocking=True)
+        if "image_raw" in batch:
+            if tf is None:
+                raise RuntimeError("raw batches need the dataset's device_transform (dataset.MVTecDataset(device_preprocess=True))")
+            images = tf(batch.pop("image_raw"), device=device)
+            masks = tf.masks(batch.pop("mask_raw"), device=device)
+            batch["image"], batch["mask"] = images, masks
+            yield batch, images, masks
+            continue
+        yield batch, batch["image"].to(device, non_blocking=True), batch["mask"].to(device, non_blocking=True)
 
 
 def train_epoch(model, train_loader, criterion, optimizer, device, epoch, step_hook=None):
