@@ -205,7 +205,7 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, long long pieces, int C,
                                                             const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, T* __restrict__ a) {
+                                                            const float* __restrict__ shift, T* __restrict__ a, int mode) {
   constexpr int PIECE = ET<T>::PIECE;
   const long long stride = (long long)gridDim.x * 256;
   long long i = blockIdx.x * 256LL + threadIdx.x;
@@ -214,10 +214,39 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
     float sc[PIECE], sh[PIECE];
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    if (mode >= 2) {
+      // block-contiguous walk, four 4-KiB rows of the block in flight (see bn_bwd_apply_premasked_kernel)
+      const long long per = (pieces + gridDim.x - 1) / gridDim.x;
+      const long long chunk = (per + 1023) / 1024 * 1024;
+      long long b0 = (long long)blockIdx.x * chunk, b1 = b0 + chunk;
+      if (b1 > pieces) b1 = pieces;
+      for (long long q = b0 + threadIdx.x; q < b1; q += 1024) {
+        float v[4][PIECE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + u * 256 < b1) {
+            if (mode == 3) Vec<T>::load_nt(y + (q + u * 256) * PIECE, v[u]);
+            else Vec<T>::load(y + (q + u * 256) * PIECE, v[u]);
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + u * 256 < b1) {
+#pragma unroll
+            for (int j = 0; j < PIECE; ++j) v[u][j] = fmaxf(fmaf(v[u][j], sc[j], sh[j]), 0.f);
+            Vec<T>::store(a + (q + u * 256) * PIECE, v[u]);
+          }
+      }
+      return;
+    }
     for (; i + stride < pieces; i += 2 * stride) {
       float v0[PIECE], v1[PIECE];
-      Vec<T>::load(y + i * PIECE, v0);
-      Vec<T>::load(y + (i + stride) * PIECE, v1);
+      if (mode == 1) {
+        Vec<T>::load_nt(y + i * PIECE, v0);
+        Vec<T>::load_nt(y + (i + stride) * PIECE, v1);
+      } else {
+        Vec<T>::load(y + i * PIECE, v0);
+        Vec<T>::load(y + (i + stride) * PIECE, v1);
+      }
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) { v0[j] = fmaxf(fmaf(v0[j], sc[j], sh[j]), 0.f); v1[j] = fmaxf(fmaf(v1[j], sc[j], sh[j]), 0.f); }
       Vec<T>::store(a + i * PIECE, v0);
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_premasked_kernel(const T* dz, const T* __restrict__ y,
                                                                      long long pieces, int C,
-                                                                     const float* __restrict__ coefs, T* dy) {
+                                                                     const float* __restrict__ coefs, T* dy, int mode) {
   constexpr int PIECE = ET<T>::PIECE;
   const long long stride = (long long)gridDim.x * 256;
   long long i = blockIdx.x * 256LL + threadIdx.x;
@@ -318,11 +347,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_premasked_kernel(const T* dz
     float A[PIECE], B[PIECE], K[PIECE];
 #pragma unroll
     for (int j = 0; j < PIECE; ++j) { A[j] = coefs[c0 + j]; B[j] = coefs[C + c0 + j]; K[j] = coefs[2 * C + c0 + j]; }
+    if (mode >= 2) {
+      // block-contiguous walk: a block streams 4 x 4 KiB of each tensor per iteration from ONE region
+      const long long per = (pieces + gridDim.x - 1) / gridDim.x;
+      const long long chunk = (per + 1023) / 1024 * 1024;
+      long long b0 = (long long)blockIdx.x * chunk, b1 = b0 + chunk;
+      if (b1 > pieces) b1 = pieces;
+      for (long long q = b0 + threadIdx.x; q < b1; q += 1024) {
+        float v[4][PIECE], g[4][PIECE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q + u * 256 < b1) {
+            if (mode == 3) Vec<T>::load_nt(y + (q + u * 256) * PIECE, v[u]);
+            else Vec<T>::load(y + (q + u * 256) * PIECE, v[u]);
+            Vec<T>::load(dz + (q + u * 256) * PIECE, g[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q + u * 256 < b1) {
+#pragma unroll
+            for (int j = 0; j < PIECE; ++j) g[u][j] = fmaf(A[j], g[u][j], fmaf(B[j], v[u][j], K[j]));
+            Vec<T>::store(dy + (q + u * 256) * PIECE, g[u]);
+          }
+        }
+      }
+      return;
+    }
     for (; i + 3 * stride < pieces; i += 4 * stride) {
       float v[4][PIECE], g[4][PIECE];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        Vec<T>::load(y + (i + u * stride) * PIECE, v[u]);
+        if (mode == 1) Vec<T>::load_nt(y + (i + u * stride) * PIECE, v[u]);
+        else Vec<T>::load(y + (i + u * stride) * PIECE, v[u]);
         Vec<T>::load(dz + (i + u * stride) * PIECE, g[u]);
       }
 #pragma unroll
@@ -380,6 +437,19 @@ int32_t launch_reduce(const void* y, const void* da, long long pixels, int C, co
 }
 
 inline int ew_blocks(long long pieces) { return (int)std::min<long long>(cdiv64(pieces, 512), 256 * 8); }
+
+// Walk of the apply passes: UNET_EW_VAR = 1 (streaming / nontemporal loads of y), 2 (every block streams ONE contiguous
+// region, four 4-KiB rows in flight), 3 (both); default 0 = grid-stride walk, plain loads.  Kept as hooks with a negative
+// result (round 4, profiles/r04_experiments.txt): looping ONE kernel over the same three 256-MiB tensors, mode 3 reads
+// 6.6 instead of 4.6 TB/s -- because the gradient tensor then stays resident in the 256-MB Infinity Cache from one
+// iteration to the next; inside the step, where the operands arrive from other kernels, the same-box A/B is +-0
+// (bn class 3.10 vs 3.10 ms).  A single-kernel loop is not evidence for an HBM-bound pass whose working set is near
+// the cache size.
+inline int ew_mode(long long elements) {
+  (void)elements;
+  const char v = unet_tuning().ew_var;
+  return (v >= '1' && v <= '3') ? v - '0' : 0;
+}
 
 }  // namespace
 
@@ -493,22 +563,23 @@ extern "C" int32_t unet_bn_relu_apply(int32_t dtype, const void* y, int64_t pixe
   UNET_REQUIRE(pixels > 0 && c > 0 && c % 8 == 0, UNET_ERR_UNSUPPORTED, "unet_bn_relu_apply: c=%d", c);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s);
+  const int ewm = ew_mode(pixels * (long long)c);
   if (dtype == UNET_BF16) {
     const long long pieces = pixels * c / 8;
     if ((256 * 8) % c == 0)
       hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a);
+                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a, ewm);
     else
       hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a);
+                         (const bf16_t*)y, pieces, c, scale, shift, (bf16_t*)a, ewm);
   } else {
     const long long pieces = pixels * c / 4;
     if ((256 * 4) % c == 0)
       hipLaunchKernelGGL((bn_relu_apply_kernel<float, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const float*)y, pieces, c, scale, shift, (float*)a);
+                         (const float*)y, pieces, c, scale, shift, (float*)a, ewm);
     else
       hipLaunchKernelGGL((bn_relu_apply_kernel<float, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const float*)y, pieces, c, scale, shift, (float*)a);
+                         (const float*)y, pieces, c, scale, shift, (float*)a, ewm);
   }
   return unet_check_launch("bn_relu_apply_kernel");
 }
@@ -598,22 +669,23 @@ extern "C" int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const vo
                        save_mean, save_istd, dgamma, dbeta, coefs, 1);
   int32_t rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
+  const int ewm = ew_mode(pixels * (long long)c);
   if (dtype == UNET_BF16) {
     const long long pieces = pixels * c / 8;
     if ((256 * 8) % c == 0)
       hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<bf16_t, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy);
+                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy, ewm);
     else
       hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<bf16_t, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy);
+                         (const bf16_t*)dz, (const bf16_t*)y, pieces, c, coefs, (bf16_t*)dy, ewm);
   } else if (dtype == UNET_F32) {
     const long long pieces = pixels * c / 4;
     if ((256 * 4) % c == 0)
       hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<float, true>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy);
+                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy, ewm);
     else
       hipLaunchKernelGGL((bn_bwd_apply_premasked_kernel<float, false>), dim3(ew_blocks(pieces)), dim3(256), 0, s,
-                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy);
+                         (const float*)dz, (const float*)y, pieces, c, coefs, (float*)dy, ewm);
   } else {
     unet_set_error("unet_bn_bwd_premasked: dtype %d", dtype);
     return UNET_ERR_BAD_ARG;

@@ -31,7 +31,7 @@ int32_t unet_check_launch(const char* what);
 
 // ---- tuning hooks: the UNET_* environment variables are read ONCE (first use); unet_tuning_reload() re-reads them
 // (same-process A/B tools).  Each field is the first character of the variable's value, 0 when unset.
-struct UnetTuning { char conv_impl, conv_var, fused_stats, convt_impl, wgrad_impl, ws_stats, dgrad_bn, pdma_pp, ws_st, ws_mfma, wgrad_xcd, conv_xcd, ws_stg, pdma_stg; };
+struct UnetTuning { char conv_impl, conv_var, fused_stats, convt_impl, wgrad_impl, ws_stats, dgrad_bn, pdma_pp, ws_st, ws_mfma, wgrad_xcd, conv_xcd, ws_stg, pdma_stg, ew_var; };
 const UnetTuning& unet_tuning();
 // CUs the persistent (one-block-per-CU, statically partitioned) kernels may count on: the device's multiprocessor count
 // minus unet_set_reserved_cus() (a data-parallel run leaves a few CUs to the RCCL all-reduce kernels that overlap the
@@ -96,6 +96,12 @@ template <> struct Vec<float> {
     f32x4 v = {o[0], o[1], o[2], o[3]};
     *reinterpret_cast<f32x4*>(p) = v;
   }
+  // streaming load: a tensor read for the LAST time (or not again for milliseconds) should not displace the hot
+  // operands of its neighbours from L2 / the Infinity Cache
+  __device__ static inline void load_nt(const float* p, float (&o)[4]) {
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
 };
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
@@ -109,6 +115,12 @@ template <> struct Vec<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
     *reinterpret_cast<bf16x8*>(p) = v;
+  }
+  __device__ static inline void load_nt(const bf16_t* p, float (&o)[8]) {
+    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    const bf16x8 v = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
   }
 };
 

@@ -292,7 +292,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
 template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ a,
-                                                               T* __restrict__ pooled, int N, int H, int W, int C) {
+                                                               T* __restrict__ pooled, int N, int H, int W, int C, int nt) {
   constexpr int PIECE = ET<T>::PIECE;
   typedef IDX idx_t;                               // int when every element index fits 31 bits (no 64-bit divisions)
   const int OH = H / 2, OW = W / 2, G = C / PIECE;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 #pragma unroll
       for (int j = 0; j < PIECE; ++j) v[k][j] = 0.f;
       if (ok) {
-        Vec<T>::load(y + o, v[k]);
+        if (nt) Vec<T>::load_nt(y + o, v[k]);
+        else Vec<T>::load(y + o, v[k]);
 #pragma unroll
         for (int j = 0; j < PIECE; ++j) v[k][j] = ET<T>::to_f(ET<T>::from_f(fmaxf(fmaf(v[k][j], sc[j], sh[j]), 0.f)));
         Vec<T>::store(a + o, v[k]);
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
                                                                const T* da_old, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ mean, T* dz,
-                                                               float* __restrict__ part, int N, int H, int W, int C) {
+                                                               float* __restrict__ part, int N, int H, int W, int C, int nt) {
   constexpr int PIECE = ET<T>::PIECE;
   typedef IDX idx_t;
   __shared__ float red[2][256][PIECE + 1];
@@ -375,10 +376,17 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
       const idx_t o1 = base + C, o2 = base + (idx_t)W * C, o3 = o2 + C;
       float gr[PIECE], yv[4][PIECE], od[4][PIECE];
       Vec<T>::load(dpooled + (((n * OH + oy) * OW + ox) * (idx_t)C + g * PIECE), gr);
-      Vec<T>::load(y + base, yv[0]);
-      Vec<T>::load(y + o1, yv[1]);
-      Vec<T>::load(y + o2, yv[2]);
-      Vec<T>::load(y + o3, yv[3]);
+      if (nt) {                                  // y is read for the last time here
+        Vec<T>::load_nt(y + base, yv[0]);
+        Vec<T>::load_nt(y + o1, yv[1]);
+        Vec<T>::load_nt(y + o2, yv[2]);
+        Vec<T>::load_nt(y + o3, yv[3]);
+      } else {
+        Vec<T>::load(y + base, yv[0]);
+        Vec<T>::load(y + o1, yv[1]);
+        Vec<T>::load(y + o2, yv[2]);
+        Vec<T>::load(y + o3, yv[3]);
+      }
       if (da_old) {
         Vec<T>::load(da_old + base, od[0]);
         Vec<T>::load(da_old + o1, od[1]);
@@ -707,18 +715,19 @@ extern "C" int32_t unet_bn_relu_pool_fwd(int32_t dtype, const void* y, int32_t n
                "unet_bn_relu_pool_fwd: c=%d h=%d w=%d", c, h, w);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_BN, 0.0, s, "bn_relu_pool_fwd_kernel");
+  const int ewnt = (unet_tuning().ew_var == '1' || unet_tuning().ew_var == '3') ? 1 : 0;   // streaming loads of y: A/B hook (+-0)
   const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
   const bool small = (long long)n * h * w * c < 0x7FFFFFFFLL;       // 32-bit element indices (no 64-bit divisions)
   if (dtype == UNET_BF16) {
     if (small)
       hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<bf16_t, int>), dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y, scale,
-                         shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
+                         shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c, ewnt);
     else
       hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<bf16_t, long long>), dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y,
-                         scale, shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c);
+                         scale, shift, (bf16_t*)a, (bf16_t*)pooled, n, h, w, c, ewnt);
   } else {
     hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<float, long long>), dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale,
-                       shift, (float*)a, (float*)pooled, n, h, w, c);
+                       shift, (float*)a, (float*)pooled, n, h, w, c, ewnt);
   }
   return unet_check_launch("bn_relu_pool_fwd_kernel");
 }
@@ -735,19 +744,20 @@ extern "C" int32_t unet_bn_relu_pool_bwd(int32_t dtype, const void* y, const voi
                "unet_bn_relu_pool_bwd: c=%d h=%d w=%d", c, h, w);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_POOL, 0.0, s, "bn_relu_pool_bwd_kernel");
+  const int ewnt = (unet_tuning().ew_var == '1' || unet_tuning().ew_var == '3') ? 1 : 0;   // streaming loads of y: A/B hook (+-0)
   const long long total = (long long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNET_BF16 ? 8 : 4));
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), POOL_BWD_MAX_BLOCKS);   // one partial per block
   const bool small = (long long)n * h * w * c < 0x7FFFFFFFLL;
   if (dtype == UNET_BF16) {
     if (small)
       hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<bf16_t, int>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y,
-                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
+                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c, ewnt);
     else
       hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<bf16_t, long long>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y,
-                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c);
+                         (const bf16_t*)dpooled, (const bf16_t*)da_old, scale, shift, mean, (bf16_t*)dz, partial, n, h, w, c, ewnt);
   } else {
     hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<float, long long>), dim3(blocks), dim3(256), 0, s, (const float*)y,
-                       (const float*)dpooled, (const float*)da_old, scale, shift, mean, (float*)dz, partial, n, h, w, c);
+                       (const float*)dpooled, (const float*)da_old, scale, shift, mean, (float*)dz, partial, n, h, w, c, ewnt);
   }
   *n_parts = blocks;
   return unet_check_launch("bn_relu_pool_bwd_kernel");

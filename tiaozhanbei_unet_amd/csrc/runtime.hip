@@ -50,6 +50,7 @@ void read_tuning() {
   g_tuning.conv_xcd = first("UNET_CONV_XCD");
   g_tuning.ws_stg = first("UNET_WS_STG");
   g_tuning.pdma_stg = first("UNET_PDMA_STG");
+  g_tuning.ew_var = first("UNET_EW_VAR");
 }
 std::mutex g_lds_mu;
 std::vector<std::pair<int, const void*>> g_lds_done;
