@@ -152,6 +152,14 @@ int32_t unet_conv3x3_first_stats(int32_t n, int32_t h, int32_t w, const float* x
 size_t unet_conv3x3_first_wgrad_workspace(int32_t n, int32_t h, int32_t w);
 int32_t unet_conv3x3_first_wgrad(int32_t n, int32_t h, int32_t w, const float* x_nchw, int32_t c_in, const void* dy,
                                  float* dw, void* workspace, size_t workspace_bytes, void* stream);
+/* The same weight gradient with the BatchNorm-backward apply of the layer (src/model.py:15, autograd) folded in: the
+ * image layer's dy has no other consumer (no data gradient towards the image), so instead of a standalone pass
+ * dy = A*dz + B*y + K the kernel streams the ReLU-masked gradient dz and the raw conv output y (both bf16 NHWC
+ * [n][h][w][64]) and forms dy -- rounded to bf16 as the pass stored it: bit-identical dW -- on its operand.
+ * coefs: DEVICE [3][64] = A, B, K, as unet_bn_bwd_premasked leaves them in its workspace when called with dy = NULL. */
+int32_t unet_conv3x3_first_wgrad_bn(int32_t n, int32_t h, int32_t w, const float* x_nchw, int32_t c_in, const void* dz,
+                                    const void* y, const float* coefs, float* dw, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* The forward convolution of DoubleConv fused with the BatchNorm batch statistics (src/model.py:14-15,
  * 17-18): y = conv(concat(src)) AND per-channel partial sums (sum, sum of squares of the stored y) written
@@ -252,7 +260,8 @@ int32_t unet_bn_relu_bwd_frozen(int32_t dtype, const void* da, const void* y, in
 /* The same backward when the producer of the gradient has already applied the ReLU mask in its own epilogue and left
  * the two per-channel sums behind (unet_head_bnrelu_bwd, unet_conv3x3_dgrad_bnrelu): dz = da*[z>0] (compute dtype,
  * NHWC), partial = fp32 [n_parts][2][c] holding sum dz and sum dz*(y - mean).  Ordered fp64 finalize -> dgamma, dbeta,
- * then ONE pass dy = A*dz + B*y + K (dy may alias dz).  workspace: 3*c floats. */
+ * then ONE pass dy = A*dz + B*y + K (dy may alias dz).  workspace: 3*c floats = A, B, K on return; dy = NULL skips the
+ * pass (dz / y may then be NULL too): the caller's consumer applies the coefficients (unet_conv3x3_first_wgrad_bn). */
 int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const void* y, int64_t pixels, int32_t c,
                               const float* gamma, const float* save_mean, const float* save_istd,
                               const float* partial, int32_t n_parts, float* dgamma, float* dbeta, void* dy,

@@ -110,3 +110,41 @@ def test_blocks_at_benchmark_shapes_bf16_against_bf16_storage_oracle(kind, cin, 
     worst = max(report, key=report.get)
     print(f"[{tag} @{size}] worst {worst} = {report[worst]:.3e}")
     assert report[worst] < 3e-2, ", ".join(f"{k}={v:.3e}" for k, v in sorted(report.items(), key=lambda kv: -kv[1])[:5])
+
+
+# ------------------------------------------------------------------ BatchNorm-backward apply folded into the image layer's wgrad
+@pytest.mark.parametrize("shape", [(4, 3, 48, 64), (2, 3, 256, 256), (3, 1, 40, 32)], ids=["48x64", "256x256", "grey_40x32"])
+def test_first_layer_wgrad_with_folded_bn_backward_is_bit_identical(shape):
+    """inc.double_conv.0..2 (src/model.py:14-16) in bf16 mode: the image layer's dy = A*dz + B*y + K has one consumer, its
+    weight gradient, so unet_conv3x3_first_wgrad_bn forms it on the operand instead of a standalone pass.  Same values,
+    same rounding: every gradient of the block is bit-identical to the unfused path (UNET_FUSE_FIRST_BN=0), and both agree
+    with the oracle."""
+    import tiaozhanbei_unet_amd as P
+    from tiaozhanbei_unet_amd import ops
+    n, c, h, w = shape
+    state = W.make_state(W.block_spec("double_conv", c, 64), 0)
+    x = W.make_input(f"r4:first{h}x{w}", shape)
+    gy = W.make_input(f"r4:first_gy{h}x{w}", (n, 64, h, w)).bfloat16().float()
+    grads = {}
+    for fused in (True, False):
+        ops.FUSE_FIRST_BN_BWD = fused
+        try:
+            m = P.DoubleConv(c, 64, precision="bf16")
+            m.load_state_dict(state)
+            m = m.to(DEV).train()
+            assert ops.first_layer_ok(x.to(DEV), m.double_conv[0], torch.bfloat16)
+            y = m(x.to(DEV))
+            y.backward(gy.to(DEV).to(y.dtype))
+            torch.cuda.synchronize()
+            grads[fused] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        finally:
+            ops.FUSE_FIRST_BN_BWD = True
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
+    _host_threads()
+    work = {"b." + k: (v.clone().requires_grad_(True) if O.is_trainable(k) else v.clone()) for k, v in state.items()}
+    with O.bf16_storage():
+        yr = O.double_conv(work, "b", O._qw(x), True)
+        yr.backward(gy)
+    for k, g in grads[True].items():
+        assert l2rel(g, work["b." + k].grad) < 3e-2, (k, l2rel(g, work["b." + k].grad))

@@ -56,6 +56,7 @@ SIGNATURES = {
     "unet_conv3x3_first_stats": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     "unet_conv3x3_first_wgrad_workspace": (_z, [_i, _i, _i]),
     "unet_conv3x3_first_wgrad": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
+    "unet_conv3x3_first_wgrad_bn": (_i, [_i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _z, _p]),
     "unet_bn_finalize_partials": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "unet_convt2x2_dgrad_bnrelu_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_convt2x2_dgrad_bnrelu_max_parts": (_z, []),

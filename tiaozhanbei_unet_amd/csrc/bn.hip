@@ -652,7 +652,7 @@ extern "C" int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const vo
                                          const float* gamma, const float* save_mean, const float* save_istd,
                                          const float* partial, int32_t n_parts, float* dgamma, float* dbeta, void* dy,
                                          void* workspace, size_t workspace_bytes, void* stream) {
-  UNET_REQUIRE(dz && y && gamma && save_mean && save_istd && partial && dgamma && dbeta && dy && workspace,
+  UNET_REQUIRE(gamma && save_mean && save_istd && partial && dgamma && dbeta && workspace && (!dy || (dz && y)),
                UNET_ERR_BAD_ARG, "unet_bn_bwd_premasked: null pointer");
   UNET_REQUIRE(pixels > 0 && c > 0 && c % FC == 0 && n_parts > 0, UNET_ERR_UNSUPPORTED, "unet_bn_bwd_premasked: c=%d", c);
   UNET_REQUIRE(workspace_bytes >= (size_t)3 * c * sizeof(float), UNET_ERR_WORKSPACE,
@@ -669,6 +669,7 @@ extern "C" int32_t unet_bn_bwd_premasked(int32_t dtype, const void* dz, const vo
                        save_mean, save_istd, dgamma, dbeta, coefs, 1);
   int32_t rc = unet_check_launch("bn_finalize_bwd_kernel");
   if (rc) return rc;
+  if (!dy) return UNET_OK;       // coefficients only: the consumer of dy applies them itself (unet_conv3x3_first_wgrad_bn)
   const int ewm = ew_mode(pixels * (long long)c);
   if (dtype == UNET_BF16) {
     const long long pieces = pixels * c / 8;

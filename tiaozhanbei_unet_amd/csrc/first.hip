@@ -83,6 +83,8 @@ struct FirstParams {
   char* y;               // [N][H][W][64] bf16 (fwd: output; wgrad: dY)
   float* part;           // fwd: BN partials [blocks][2][64] (may be NULL); wgrad: [blocks][64][32]
   int N, CI, H, W;
+  const char* y_raw;     // wgrad<BNB>: the layer's raw conv output (P.y is then the ReLU-masked gradient dz)
+  const float* coefs;    // wgrad<BNB>: [3][64] A, B, K of dy = A*dz + B*y + K
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -247,16 +249,25 @@ __device__ inline bf16x8 tr_frag2(const char* base, int off0, int off1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 4) void first_wgrad_kernel(const FirstParams P) {
-  // per wave: 2 x WU 2-KiB dY segments (16 pixels x 64 channels bf16); reused for the block reduction
-  __shared__ __attribute__((aligned(16))) char smem[4 * FIRST_CO * 32 * 4];   // 32 KiB >= the 16 KiB of DMA buffers
+// BNB (round 4): the BatchNorm-backward apply of this layer rides along.  The image layer is the one layer whose dy has a
+// SINGLE consumer -- this kernel; there is no data gradient towards the image -- so the standalone pass
+// dy = A*dz + B*y + K (read dz, read y, write dy: 805 MB at bs = 32, 256 x 256) disappears: the kernel streams the masked
+// gradient dz AND the raw conv output y (segment for segment, side by side in the wave's LDS buffer), and a lane -- which
+// holds 8 pixels of ONE channel after the transposed read -- forms dy with that channel's three coefficients and rounds
+// it to bf16 exactly as the apply pass stored it: the same MFMA operands, bit-identical dW.
+template <bool BNB>
+__global__ __launch_bounds__(256, BNB ? 2 : 4) void first_wgrad_kernel(const FirstParams P) {
+  // per wave: 2 x WU 2-KiB dY segments (16 pixels x 64 channels bf16) [BNB: + the y segment behind each]; reused for
+  // the block reduction
+  constexpr int SEGB = BNB ? 4096 : 2048;
+  __shared__ __attribute__((aligned(16))) char smem[BNB ? 4 * 2 * 2 * 4096 : 4 * FIRST_CO * 32 * 4];   // >= 32 KiB
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const int K = 9 * P.CI;
   const int HW = P.H * P.W;
   constexpr int WU = 2;                           // segments per iteration (two more in flight behind them)
-  char* const wbuf = smem + wave * (WU * 2 * 2048);
+  char* const wbuf = smem + wave * (WU * 2 * SEGB);
 
   // B operand geometry: lane (n = l31 = k index, hh): pixels 8hh .. 8hh+7 of the segment
   const bool kvalid = l31 < K;
@@ -297,7 +308,15 @@ __global__ __launch_bounds__(256, 4) void first_wgrad_kernel(const FirstParams P
         0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(wbuf + slot * 2048 + i * 1024), 16, dsrc[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(wbuf + slot * SEGB + i * 1024), 16, dsrc[i], 0, 0, 0);
+    if constexpr (BNB) {
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(P.y_raw + pix0 * (FIRST_CO * 2)), (short)0, (int)std::min<long long>(2048, dy_total - pix0 * (FIRST_CO * 2)),
+          0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_void*)(wbuf + slot * SEGB + 2048 + i * 1024), 16, dsrc[i], 0, 0, 0);
+    }
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(P.x + (size_t)n * P.CI * HW), (short)0, (int)img_bytes, 0x00020000);
     const int x0 = seg * 16;
@@ -323,16 +342,25 @@ __global__ __launch_bounds__(256, 4) void first_wgrad_kernel(const FirstParams P
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[wr][r] = 0.f;
 
-  // every iteration issues exactly WU x (2 DMAs + 8 loads) -- segments past the end become out-of-range no-ops --
-  // so the wait that retires the CURRENT iteration's operands is a constant vmcnt(10*WU)
+  // every iteration issues exactly WU x (2 [BNB: 4] DMAs + 8 loads) -- segments past the end become out-of-range no-ops --
+  // so the wait that retires the CURRENT iteration's operands is a constant vmcnt(NV*WU)
+  constexpr int NV = BNB ? 12 : 10;
+  float cA[2], cB[2], cK[2];                      // BNB: coefficients of this lane's channel in each 32-channel half
+  if constexpr (BNB) {
+#pragma unroll
+    for (int wr = 0; wr < 2; ++wr) {
+      const int ch = wr * 32 + 16 * (g & 1) + i16;
+      cA[wr] = P.coefs[ch]; cB[wr] = P.coefs[FIRST_CO + ch]; cK[wr] = P.coefs[2 * FIRST_CO + ch];
+    }
+  }
   auto issue_or_skip = [&](SegPos q, int slot, float (&xv)[8]) {
     if (q.n < P.N) {
       issue(q, slot, xv);
     } else {
       const __amdgpu_buffer_rsrc_t nul = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, 0, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(nul, (lds_void*)(wbuf + slot * 2048 + i * 1024), 16, OOB, 0, 0, 0);
+      for (int i = 0; i < (BNB ? 4 : 2); ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(nul, (lds_void*)(wbuf + slot * SEGB + i * 1024), 16, OOB, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nul, OOB, 0, 0));
     }
@@ -348,16 +376,22 @@ __global__ __launch_bounds__(256, 4) void first_wgrad_kernel(const FirstParams P
     const SegPos nxt = seg_step(cur, wk.dseg, wk.dy, wk.dn, segs_row, P.H);
 #pragma unroll
     for (int i = 0; i < WU; ++i) issue_or_skip(seg_step(nxt, i, 0, 0, segs_row, P.H), (buf ^ 1) * WU + i, xn[i]);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * WU) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV * WU) : "memory");
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
       bf16x8 fb;
 #pragma unroll
       for (int e = 0; e < 8; ++e) fb[e] = (bf16_t)xc[i][e];          // zeros for a skipped segment
-      const char* sb = wbuf + (buf * WU + i) * 2048;
+      const char* sb = wbuf + (buf * WU + i) * SEGB;
 #pragma unroll
       for (int wr = 0; wr < 2; ++wr) {
-        const bf16x8 fa = tr_frag2(sb, aoff[wr], aoff[wr] + 4 * 128);
+        bf16x8 fa = tr_frag2(sb, aoff[wr], aoff[wr] + 4 * 128);
+        if constexpr (BNB) {
+          const bf16x8 fy = tr_frag2(sb + 2048, aoff[wr], aoff[wr] + 4 * 128);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)            // dy as bn_bwd_apply_premasked_kernel stores it
+            fa[e] = (bf16_t)fmaf(cA[wr], (float)fa[e], fmaf(cB[wr], (float)fy[e], cK[wr]));
+        }
         acc[wr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[wr], 0, 0, 0);
       }
     }
@@ -433,7 +467,7 @@ extern "C" int32_t unet_conv3x3_first_stats(int32_t n, int32_t h, int32_t w, con
   UNET_REQUIRE((long long)c_in * h * w * 4 < 0x7FFFFFFFLL, UNET_ERR_UNSUPPORTED, "unet_conv3x3_first_stats: image too large");
   const long long units = (long long)n * h * (w / 16);
   const int blocks = first_blocks(units, 2, 3);
-  FirstParams P{x, weight, (char*)y, partial, n, c_in, h, w};
+  FirstParams P{x, weight, (char*)y, partial, n, c_in, h, w, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_CONV_FWD, 2.0 * n * h * w * (double)FIRST_CO * c_in * 9, s);
   hipLaunchKernelGGL(first_fwd_kernel, dim3(blocks), dim3(256), 0, s, P);
@@ -446,23 +480,38 @@ extern "C" size_t unet_conv3x3_first_wgrad_workspace(int32_t n, int32_t h, int32
   return (size_t)first_blocks(units, 2, 4) * FIRST_CO * 32 * sizeof(float);
 }
 
-extern "C" int32_t unet_conv3x3_first_wgrad(int32_t n, int32_t h, int32_t w, const float* x, int32_t c_in,
-                                            const void* dy, float* dw, void* workspace, size_t workspace_bytes,
-                                            void* stream) {
-  UNET_REQUIRE(x && dy && dw && workspace, UNET_ERR_BAD_ARG, "unet_conv3x3_first_wgrad: null pointer");
+static int32_t first_wgrad_impl(int32_t n, int32_t h, int32_t w, const float* x, int32_t c_in, const void* dy, const void* y_raw,
+                                const float* coefs, float* dw, void* workspace, size_t workspace_bytes, void* stream,
+                                const char* what) {
+  UNET_REQUIRE(x && dy && dw && workspace, UNET_ERR_BAD_ARG, "%s: null pointer", what);
   UNET_REQUIRE(n > 0 && unet_conv3x3_first_supported(c_in, FIRST_CO, h, w), UNET_ERR_UNSUPPORTED,
-               "unet_conv3x3_first_wgrad: n=%d c_in=%d h=%d w=%d", n, c_in, h, w);
-  UNET_REQUIRE((long long)c_in * h * w * 4 < 0x7FFFFFFFLL, UNET_ERR_UNSUPPORTED, "unet_conv3x3_first_wgrad: image too large");
-  UNET_REQUIRE(workspace_bytes >= unet_conv3x3_first_wgrad_workspace(n, h, w), UNET_ERR_WORKSPACE,
-               "unet_conv3x3_first_wgrad: workspace too small");
+               "%s: n=%d c_in=%d h=%d w=%d", what, n, c_in, h, w);
+  UNET_REQUIRE((long long)c_in * h * w * 4 < 0x7FFFFFFFLL, UNET_ERR_UNSUPPORTED, "%s: image too large", what);
+  UNET_REQUIRE(workspace_bytes >= unet_conv3x3_first_wgrad_workspace(n, h, w), UNET_ERR_WORKSPACE, "%s: workspace too small", what);
   const long long units = (long long)n * h * (w / 16);
   const int blocks = first_blocks(units, 2, 4);
-  FirstParams P{x, nullptr, (char*)const_cast<void*>(dy), (float*)workspace, n, c_in, h, w};
+  FirstParams P{x, nullptr, (char*)const_cast<void*>(dy), (float*)workspace, n, c_in, h, w, (const char*)y_raw, coefs};
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(UNET_K_CONV_WGRAD, 2.0 * n * h * w * (double)FIRST_CO * c_in * 9, s);
-  hipLaunchKernelGGL(first_wgrad_kernel, dim3(blocks), dim3(256), 0, s, P);
+  if (y_raw) hipLaunchKernelGGL(first_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(first_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, s, P);
   int32_t rc = unet_check_launch("first_wgrad_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(FIRST_CO), dim3(256), 0, s, (const float*)workspace, blocks, c_in, dw);
   return unet_check_launch("first_wgrad_reduce_kernel");
+}
+
+extern "C" int32_t unet_conv3x3_first_wgrad(int32_t n, int32_t h, int32_t w, const float* x, int32_t c_in,
+                                            const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  return first_wgrad_impl(n, h, w, x, c_in, dy, nullptr, nullptr, dw, workspace, workspace_bytes, stream,
+                          "unet_conv3x3_first_wgrad");
+}
+
+extern "C" int32_t unet_conv3x3_first_wgrad_bn(int32_t n, int32_t h, int32_t w, const float* x, int32_t c_in,
+                                               const void* dz, const void* y, const float* coefs, float* dw,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  UNET_REQUIRE(y && coefs, UNET_ERR_BAD_ARG, "unet_conv3x3_first_wgrad_bn: null pointer");
+  return first_wgrad_impl(n, h, w, x, c_in, dz, y, coefs, dw, workspace, workspace_bytes, stream,
+                          "unet_conv3x3_first_wgrad_bn");
 }

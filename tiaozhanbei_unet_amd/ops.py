@@ -707,6 +707,24 @@ class FirstConvBnRelu(torch.autograd.Function):
         n, ci, h, w = x.shape
         co = weight.shape[0]
         lib, st, dev = L.lib(), _stream(), x.device
+        link = ctx.out_link
+        if FUSE_FIRST_BN_BWD and link is not None and link.dz_ptr and link.dz_ptr == da.data_ptr() and da.dtype == dtype \
+                and _is_nhwc(da) and ctx.training and ctx.needs_input_grad[1]:
+            # The image layer's dy has ONE consumer, its weight gradient (nothing flows back into the image): the
+            # BatchNorm-backward apply pass is folded into that kernel's operand -- finalize only (dy = NULL), then
+            # unet_conv3x3_first_wgrad_bn streams dz and y and forms dy = A*dz + B*y + K per lane (bit-identical dW).
+            dgb = (grad_out(gamma.shape, dev, gamma.data_ptr()), grad_out(gamma.shape, dev, ctx.keys[1]))
+            cf = torch.empty(3 * co, dtype=torch.float32, device=dev)
+            L.check(lib.unet_bn_bwd_premasked(dt, None, None, n * h * w, co, _ptr(gamma), _ptr(coef[0]), _ptr(coef[1]),
+                                              _ptr(link.partial), link.n_parts, _ptr(dgb[0]), _ptr(dgb[1]), None, _ptr(cf),
+                                              cf.numel() * 4, st), "unet_bn_bwd_premasked(coefficients)")
+            link.y = link.coef = link.partial = None
+            link.dz_ptr = 0
+            dw = grad_out(weight.shape, dev, ctx.keys[0])
+            ws2 = _workspace(lib.unet_conv3x3_first_wgrad_workspace(n, h, w), dev)
+            L.check(lib.unet_conv3x3_first_wgrad_bn(n, h, w, _ptr(x), ci, _ptr(da), _ptr(y), _ptr(cf), _ptr(dw), _ptr(ws2),
+                                                    ws2.numel(), st), "unet_conv3x3_first_wgrad_bn")
+            return None, dw, dgb[0], dgb[1], None, None, None, None, None
         dy, dgb = _bn_relu_backward(lib, dt, dtype, da, y, gamma, coef, ctx.out_link, ctx.out_sink, dev, st,
                                     frozen=not ctx.training, beta_key=ctx.keys[1])
         dw = None
@@ -720,6 +738,7 @@ class FirstConvBnRelu(torch.autograd.Function):
 
 
 FIRST_LAYER_KERNELS = __import__("os").environ.get("UNET_FIRST_LAYER", "1") != "0"
+FUSE_FIRST_BN_BWD = __import__("os").environ.get("UNET_FUSE_FIRST_BN", "1") != "0"      # tuning hook (A/B runs)
 
 
 def first_layer_ok(x: torch.Tensor, conv, dtype) -> bool:
