@@ -14,4 +14,12 @@ REFERENCE ITSELF, produced in the build container by importing
 (``tools/make_goldens.py``) and committed as small ``.npz`` fixtures under
 ``tests/golden/``.  ``tests/test_oracle_golden.py`` checks every oracle function
 against those fixtures.
+
+``pil_oracle.py`` (round 4) restates the image transforms of the loaders
+(src/dataset.py:130-154, src/kolektorsdd_dataset.py:133-155).  The reference
+runs them through torchvision on PIL images, i.e. inside Pillow -- a
+third-party dependency, not part of ``/root/reference``; the restatement is
+pinned by fixtures Pillow 12.2.0 itself produced in the build container
+(``tools/make_goldens_aug.py`` -> ``tests/golden/aug_pil.npz``,
+``tests/test_oracle_aug_golden.py``).
 """
