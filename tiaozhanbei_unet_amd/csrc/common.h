@@ -31,7 +31,7 @@ int32_t unet_check_launch(const char* what);
 
 // ---- tuning hooks: the UNET_* environment variables are read ONCE (first use); unet_tuning_reload() re-reads them
 // (same-process A/B tools).  Each field is the first character of the variable's value, 0 when unset.
-struct UnetTuning { char conv_impl, conv_var, fused_stats, convt_impl, wgrad_impl, ws_stats, dgrad_bn, pdma_pp, ws_st, ws_mfma, wgrad_xcd, conv_xcd, ws_stg, pdma_stg, ew_var; };
+struct UnetTuning { char conv_impl, conv_var, fused_stats, convt_impl, wgrad_impl, ws_stats, dgrad_bn, pdma_pp, ws_st, ws_mfma, wgrad_xcd, conv_xcd, ws_stg, pdma_stg, ew_var, pdma_pair; };
 const UnetTuning& unet_tuning();
 // CUs the persistent (one-block-per-CU, statically partitioned) kernels may count on: the device's multiprocessor count
 // minus unet_set_reserved_cus() (a data-parallel run leaves a few CUs to the RCCL all-reduce kernels that overlap the

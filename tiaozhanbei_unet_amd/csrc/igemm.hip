@@ -916,14 +916,15 @@ __device__ __forceinline__ void pdma_item(int wk, int n_tiles, int c, int& cot, 
   cot = sg * c + (rem - tile * c);
 }
 
-template <int BN>
+template <int BN, bool PAIR = false>
 struct CfgP {
   static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
   static constexpr int PSTR = 160, PPP = 10, RS = HW * PSTR;
   static constexpr int A_INSTR = (HH * HW * PPP + 63) / 64;         // 51 wave-instructions of 1 KiB
   static constexpr int A_BYTES = A_INSTR * 1024;
   static constexpr int NDA = (A_INSTR + 7) / 8;                      // 7 per wave
-  static constexpr int W_BYTES = BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128) or 1 (BN 64) per wave
+  // PAIR (BN = 64): a ring slot holds the slabs of TWO consecutive taps (a step = two taps between barriers)
+  static constexpr int W_BYTES = (PAIR ? 2 : 1) * BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128, PAIR) or 1 (BN 64) per wave
   static constexpr int NSLOT = 3;
   // the weight ring sits FIRST: slot * W_BYTES (<= 32 KiB) then folds into the 16-bit offset field of the fragment
   // ds_reads (behind the patches, at 102 KiB, every read cost a v_add and the tap a spilled-SGPR v_readlane)
@@ -948,9 +949,17 @@ struct CfgP {
 #ifndef PDMA_DEFER128
 #define PDMA_DEFER128 (!PP && !BNBWD)
 #endif
-template <int BN, bool BNBWD = false, bool PP = false>
+// PAIR (round 4; BN = 64, exactly two 64-channel chunks = the 128 -> 64 layers at 256 x 256 and the 128 -> 64 data
+// gradient): with 64-channel tiles a tap is only 16 MFMAs per wave, and the stamps (profiles/r04_pdma64_stamps.txt) put
+// ~800 of its 1 300 cycles into what a tap costs regardless of its size -- the barrier skew, the DMA-issue burst, the
+// fragment-read latency in front of the first MFMA.  A STEP is therefore two consecutive taps of the 18 of a work item
+// (9 steps; step 4 straddles the chunks): one barrier, one counted wait and one DMA burst per 32 MFMAs, as in the
+// 128-channel kernel; a ring slot holds both taps' weight slabs (16 KiB, the 128-channel ring), the second tap's
+// fragments are fetched behind the first tap's MFMAs.  Same accumulation order, bit-identical outputs.
+template <int BN, bool BNBWD = false, bool PP = false, bool PAIR = false>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
-  using C = CfgP<BN>;
+  static_assert(!PAIR || (BN == 64 && !PP), "pair steps: the lock-step 64-channel kernel");
+  using C = CfgP<BN, PAIR>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -989,7 +998,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     const int edge = (hy == 0) | ((hy == C::HH - 1) << 1) | ((hx == 0) << 2) | ((hx == C::HW - 1) << 3);
     a_code[j] = (pix < C::HH * C::HW && part < 8) ? (hy | (hx << 8) | (part << 16) | (edge << 24)) : -1;
   }
-  unsigned w_g[C::NDW];
+  unsigned w_g[C::NDW];                          // (PAIR: both instructions of a step use w_g[0], rows 0-63 of a tap's slab)
 #pragma unroll
   for (int j = 0; j < C::NDW; ++j) {
     const int q = (j * 8 + wave) * 64 + lane;
@@ -1082,6 +1091,18 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
   };
 
+  // PAIR: the slabs of linear tap-steps (sA, sA + 1) of the work item whose first weight row is `wbase` into ring slot `slot`
+  // (rows 0-63: tap A, rows 64-127: tap B; the same per-lane row / piece offsets, two scalar bases)
+  auto dma_w2 = [&](unsigned wbase, int sA, int slot, bool live) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int sj = sA + j, cj = sj / 9, tj = sj - cj * 9;
+      const unsigned soff = live ? wbase + (unsigned)tj * w_tap_stride + (unsigned)cj * 128 : 0u;
+      char* dst = live ? smem + C::W_BASE + slot * C::W_BYTES + j * (BN * 128) + wave * 1024 : smem + C::DUMMY;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, live ? w_g[0] : OOB, soff, 0, 0);
+    }
+  };
+
   f32x4 acc[C::CT][4];
   // One tap = two 32-channel half-steps (ks) of CT x 4 MFMAs.  The fragment reads are software-pipelined BY HAND and
   // pinned with sched_barriers: left alone, hipcc funnels the weight fragments through one register quad and waits
@@ -1138,6 +1159,46 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     }
   };
 
+  // PAIR: two taps back to back (A then B: the accumulation order of two single taps); tap B's fragments are requested
+  // behind tap A's MFMAs, so only the first half-step of a step waits for LDS
+  auto compute2 = [&](int pbufA, int toffA, int pbufB, int toffB, int slot) {
+    const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
+    const char* pbA = smem + pbufA + toffA;
+    const char* pbB = smem + pbufB + toffB;
+    auto ra = [&](int tb, int ks, int ct) { return *reinterpret_cast<const bf16x8*>(pa + tb * (BN * 128) + aoff[ct][ks]); };
+    auto rb = [&](const char* pb, int ks, int pt) { return *reinterpret_cast<const bf16x8*>(pb + boff[pt] + ks * 64); };
+    auto mm = [&](int ct, const bf16x8& fa_, const bf16x8 (&fb_)[4]) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_, fb_[pt], acc[ct][pt], 0, 0, 0);
+    };
+    bf16x8 f0[4], f1[4], g0[4], g1[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) f0[pt] = rb(pbA, 0, pt);
+    const bf16x8 a0 = ra(0, 0, 0), a1 = ra(0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) f1[pt] = rb(pbA, 1, pt);
+    const bf16x8 a2 = ra(0, 1, 0), a3 = ra(0, 1, 1);
+    mm(0, a0, f0);
+    mm(1, a1, f0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) g0[pt] = rb(pbB, 0, pt);
+    const bf16x8 c0 = ra(1, 0, 0), c1 = ra(1, 0, 1);
+    mm(0, a2, f1);
+    mm(1, a3, f1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) g1[pt] = rb(pbB, 1, pt);
+    const bf16x8 c2 = ra(1, 1, 0), c3 = ra(1, 1, 1);
+    mm(0, c0, g0);
+    mm(1, c1, g0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0, c2, g1);
+    mm(1, c3, g1);
+  };
+
   // PP: the same tap as two halves -- every fragment of the tap into registers, then nothing but MFMAs
   bf16x8 fa[2][C::CT], fb[2][4];
   auto load_frags = [&](int pbuf, int toff, int slot) {
@@ -1165,8 +1226,13 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   setup_dma(logical);
 #pragma unroll
   for (int j = 0; j < C::NDA; ++j) dma_patch(0, j, 0, true);
-  dma_w(d_wbase, 0, 0, 0, true);
-  dma_w(d_wbase, 0, 1, 1, true);
+  if constexpr (PAIR) {
+    dma_w2(d_wbase, 0, 0, true);
+    dma_w2(d_wbase, 2, 1, true);
+  } else {
+    dma_w(d_wbase, 0, 0, 0, true);
+    dma_w(d_wbase, 0, 1, 1, true);
+  }
   if constexpr (PP) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");      // patch 0 + W(0) landed; W(1) in flight
     __builtin_amdgcn_s_barrier();
@@ -1222,6 +1288,53 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[a][b][q] = 0.f;
 
+    if constexpr (PAIR) {
+      // 9 steps of two taps; chunk 0 lives in patch buffer 0, chunk 1 in buffer 1 (nchunks == 2: the launcher's condition).
+      // Patch pieces: steps 0-3 bring THIS item's chunk 1 (2, 2, 2, 1 pieces per wave), steps 5-8 the NEXT item's chunk 0
+      // (buffer 0 is read for the last time by step 4); the weights of step d + 2 follow the pieces of step d.
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        constexpr int NPIECE[9] = {2, 2, 2, 1, 0, 2, 2, 2, 1};
+        if (d == 5) {                              // from here on the DMA stream belongs to the next work item
+          d_live = has_next;
+          if (has_next) setup_dma(wk + G);
+        }
+        // W(d) was issued two steps ago; younger: the previous step's patch pieces + NDW weight DMAs [+ the output stores of
+        // the previous item's epilogue].  Step 4 also needs chunk 1's LAST patch piece, issued in step 3 in front of W(5)
+        if (d == 0) {
+          if (after_epilogue) {
+            if (P.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + C::NST + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + C::NST) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");
+          }
+        } else if (d == 4) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");
+        } else {
+          const int np = NPIECE[d == 0 ? 0 : d - 1];
+          if (np == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + 2) : "memory");
+          else if (np == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NDW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        auto issue_dma = [&]() {
+          const int first = d < 4 ? 2 * d : 2 * (d - 5);           // (steps 0-3 / 5-8: pieces 0,1 | 2,3 | 4,5 | 6)
+#pragma unroll
+          for (int q = 0; q < NPIECE[d]; ++q) {
+            if (d < 4) dma_patch(1, first + q, 1, true);
+            else dma_patch(0, first + q, 0, d_live);
+          }
+          if (d + 2 < 9) dma_w2(c_wbase, 2 * (d + 2), (d + 2) % 3, true);
+          else dma_w2(d_wbase, 2 * (d + 2 - 9), (d + 2) % 3, d_live);
+        };
+        if (!late_dma) issue_dma();
+        const int sA = 2 * d, sB = 2 * d + 1;
+        const int cA = sA / 9, tA = sA % 9, cB = sB / 9, tB = sB % 9;
+        compute2(C::A_BASE + cA * C::A_BYTES, (tA / 3) * C::RS + (tA % 3) * C::PSTR,
+                 C::A_BASE + cB * C::A_BYTES, (tB / 3) * C::RS + (tB % 3) * C::PSTR, d % 3);
+        if (late_dma) issue_dma();
+      }
+    } else
     for (int c = 0; c < nchunks; ++c) {
       const bool last = c + 1 == nchunks;
       if (last) {                                  // from here on the DMA stream belongs to the next work item
@@ -1587,6 +1700,8 @@ __global__ __launch_bounds__(512, 1) void conv3_pp128_kernel(const IgemmParams P
 __global__ __launch_bounds__(512, 1) void conv3_pp64_kernel(const IgemmParams P) { conv3_pdma_body<64, false, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pp128_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<128, true, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pp64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64x2_kernel(const IgemmParams P) { conv3_pdma_body<64, false, false, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64x2_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, false, true>(P); }
 
 #ifdef PDMA_STAMPS
 void* g_pdma_debug = nullptr;      // (also read by wgrad.hip)
@@ -1614,11 +1729,15 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   P.pdma_stagger = unet_tuning().pdma_stg != '0';           // default on: +3..8 % on the lock-step layers (profiles/r03_pdma_stagger.txt)
   const char ppv = unet_tuning().pdma_pp;
   const bool pp = ppv == '1' || (ppv != '0' && BN == 128 && P.Ctot >= 512);
-  auto kern = pp ? (bnbwd ? (BN == 128 ? conv3_pp128_bnbwd_kernel : conv3_pp64_bnbwd_kernel)
-                          : (BN == 128 ? conv3_pp128_kernel : conv3_pp64_kernel))
-                 : (bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
-                          : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel));
-  unet_set_max_lds(reinterpret_cast<const void*>(kern), C::LDS);
+  // two taps per step for 64-channel tiles over exactly two chunks (UNET_PDMA_PAIR=0: one tap per step, for A/B)
+  const bool pair = BN == 64 && !pp && P.Ctot == 128 && unet_tuning().pdma_pair != '0';
+  auto kern = pair ? (bnbwd ? conv3_pdma64x2_bnbwd_kernel : conv3_pdma64x2_kernel)
+              : pp ? (bnbwd ? (BN == 128 ? conv3_pp128_bnbwd_kernel : conv3_pp64_bnbwd_kernel)
+                            : (BN == 128 ? conv3_pp128_kernel : conv3_pp64_kernel))
+                   : (bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
+                            : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel));
+  const int lds_bytes = pair ? CfgP<64, true>::LDS : C::LDS;
+  unet_set_max_lds(reinterpret_cast<const void*>(kern), lds_bytes);
   const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);
   const long long stat_bytes = (long long)P.N * P.tilesY * P.tilesX * 2 * P.Cout * 4;
@@ -1649,7 +1768,7 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   const double alg_bytes = 2.0 * (px * (P.Ctot + P.Cout * (1.0 + (bnbwd ? 1 : 0) + (P.accumulate ? 1 : 0))) + 9.0 * P.Ctot * P.Cout);
   ProfScope prof(kclass, flops, s, bnbwd ? (BN == 128 ? "conv3_pdma128_bnbwd_kernel" : "conv3_pdma64_bnbwd_kernel")
                                           : (BN == 128 ? "conv3_pdma128_kernel" : "conv3_pdma64_kernel"), alg_bytes);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS, s, P);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, P);
   return unet_check_launch("conv3_pdma_kernel");
 }
 

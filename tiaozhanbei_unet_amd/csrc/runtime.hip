@@ -51,6 +51,7 @@ void read_tuning() {
   g_tuning.ws_stg = first("UNET_WS_STG");
   g_tuning.pdma_stg = first("UNET_PDMA_STG");
   g_tuning.ew_var = first("UNET_EW_VAR");
+  g_tuning.pdma_pair = first("UNET_PDMA_PAIR");
 }
 std::mutex g_lds_mu;
 std::vector<std::pair<int, const void*>> g_lds_done;
