@@ -18,7 +18,7 @@ Prints ONE JSON line (rank 0) with the driver's contract plus:
   roofline     -- the dominant KERNEL (most event time among the MFMA kernels), timed live with hipEvents on its own
                   stream (libunet_hip's per-launch brackets) against the dense MFMA peak of the dtype; `traffic` =
                   HBM bytes per launch of that kernel from the committed PMC passes of this same command
-                  (profiles/r03_pmc_traffic.json, tools/pmc_traffic.sh; quoted only when that summary was taken from
+                  (profiles/r04_pmc_traffic.json, tools/pmc_traffic.sh; quoted only when that summary was taken from
                   THIS build -- same sha256 of csrc/ -- else null), beside the algorithmic bytes of the same launches;
   cpu_baseline -- the CPU oracle (a port of the reference's train step) timed on this box's host cores
                   on a bounded sample (N=1 only).
@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_IMG_256 = {"anomaly_unet": 158.637, "unet": 96.335}      # SURVEY 8(d), forward, 256x256
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def csrc_sha16():

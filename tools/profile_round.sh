@@ -2,9 +2,9 @@
 # end-of-round evidence: bench lines (default / fp32 UNet / SSIM), rocprofv3 kernel-trace summaries (two decoder streams and
 # single stream), PMC traffic.  Everything lands under gpurun_out/; copy what is to be judged into profiles/.
 #   tools/profile_round.sh r02_g
-tag=${1:-r02}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-bash tools/pmc_traffic.sh          # first: bench.py quotes roofline.traffic from the summary of THIS build (csrc hash)
+PMC_TAG=${PMC_TAG:-r04} bash tools/pmc_traffic.sh          # first: bench.py quotes roofline.traffic from the summary of THIS build (csrc hash)
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python3 bench.py --model unet --precision fp32 --batch 16 --no-cpu-baseline > gpurun_out/${tag}_bench_unet_fp32.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --ssim --no-cpu-baseline > gpurun_out/${tag}_bench_ssim.json 2>> gpurun_out/${tag}_bench.err
