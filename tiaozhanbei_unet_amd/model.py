@@ -396,7 +396,10 @@ class AnomalyUNet(_HipBlock):
         main.wait_stream(side)
         anomaly_map.record_stream(main)
         if torch.is_grad_enabled() and (reconstruction.requires_grad or anomaly_map.requires_grad):
-            reconstruction, anomaly_map = _QuietStreamMismatch.apply(reconstruction, anomaly_map)
+            setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if setter is not None and os.environ.get("UNET_KEEP_STREAM_WARNING", "0") == "0":
+                setter(False)                    # (the engine checks when a backward pass STARTS: see _QuietStreamMismatch)
+                reconstruction, anomaly_map = _QuietStreamMismatch.apply(reconstruction, anomaly_map)
         return reconstruction, anomaly_map
 
 
@@ -404,9 +407,10 @@ class _QuietStreamMismatch(torch.autograd.Function):
     """Identity on the two outputs of a two-stream AnomalyUNet forward.  The segmentation decoder's weight gradients are
     produced on the side stream while their AccumulateGrad nodes belong to the stream the parameters live on: autograd
     orders the two with an event wait -- exactly the dependency the optimiser step needs -- and warns about it.  The
-    wait is wanted, the warning is not: this node runs FIRST in the backward pass, switches the warning off and queues an
-    engine callback that switches it back on when THIS backward pass has finished -- the process-wide setting is
-    untouched outside the model's own backward (``UNET_KEEP_STREAM_WARNING=1`` leaves it alone altogether)."""
+    wait is wanted, the warning is not.  The engine looks at the switch when a backward pass starts, so the forward pass
+    switches the warning off and this node -- part of that backward pass -- queues an engine callback that switches it
+    back on when the pass has finished: the process-wide setting is off only between this model's forward and the end of
+    its backward (``UNET_KEEP_STREAM_WARNING=1`` leaves it alone altogether)."""
 
     @staticmethod
     def forward(ctx, a, b):
@@ -415,7 +419,6 @@ class _QuietStreamMismatch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, gb):
         setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if setter is not None and os.environ.get("UNET_KEEP_STREAM_WARNING", "0") == "0":
-            setter(False)
+        if setter is not None:
             torch.autograd.Variable._execution_engine.queue_callback(lambda: setter(True))
         return ga, gb
