@@ -93,3 +93,24 @@ def test_rotation_matrix_fixed_point_equals_the_oracles():
         fix = lambda v: int(math.floor(v * 65536.0 + 0.5))    # noqa: E731
         want = [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
         assert rotation_matrix_fixed(w, h, ang) == want
+
+
+def test_device_transform_draws_follow_the_reference_distributions():
+    """augment.DeviceTransform.draw: the per-sample parameters of src/dataset.py:136-138 (flip p = 0.5, angle U(-10, 10),
+    ColorJitter: a permutation of the four operations, brightness / contrast / saturation U(0.9, 1.1), hue U(-0.05, 0.05));
+    seeded draws repeat, the Kolektor variant narrows the angle (src/kolektorsdd_dataset.py:139)."""
+    from tiaozhanbei_unet_amd.augment import DeviceTransform, jitter_table, JITTER_DTYPE
+    tf = DeviceTransform(256, train=True, seed=5)
+    p = tf.draw(400)
+    assert 0.35 < sum(p["flips"]) / 400 < 0.65
+    assert all(-10.0 <= a <= 10.0 for a in p["angles"]) and max(p["angles"]) > 8 and min(p["angles"]) < -8
+    assert all(sorted(o) == [0, 1, 2, 3] for o in p["orders"]) and len({tuple(o) for o in p["orders"]}) == 24
+    for k in ("brightness", "contrast", "saturation"):
+        assert all(0.9 <= v <= 1.1 for v in p[k]) and max(p[k]) > 1.08 and min(p[k]) < 0.92
+    assert all(-0.05 <= v <= 0.05 for v in p["hue"])
+    again = DeviceTransform(256, train=True, seed=5).draw(400)
+    assert again == p
+    k = DeviceTransform((1408, 512), train=True, degrees=5, seed=1).draw(200)
+    assert all(-5.0 <= a <= 5.0 for a in k["angles"])
+    tab = jitter_table(p["orders"][:3], p["brightness"][:3], p["contrast"][:3], p["saturation"][:3], [0.031, -0.05, 0.0])
+    assert tab.dtype == JITTER_DTYPE and tab.itemsize == 32 and tab["hue_shift"].tolist() == [7, 244, 0]
