@@ -916,7 +916,7 @@ __device__ __forceinline__ void pdma_item(int wk, int n_tiles, int c, int& cot, 
   cot = sg * c + (rem - tile * c);
 }
 
-template <int BN, bool PAIR = false>
+template <int BN, bool PAIR = false, bool ROW3 = false>
 struct CfgP {
   static constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
   static constexpr int PSTR = 160, PPP = 10, RS = HW * PSTR;
@@ -924,8 +924,10 @@ struct CfgP {
   static constexpr int A_BYTES = A_INSTR * 1024;
   static constexpr int NDA = (A_INSTR + 7) / 8;                      // 7 per wave
   // PAIR (BN = 64): a ring slot holds the slabs of TWO consecutive taps (a step = two taps between barriers)
-  static constexpr int W_BYTES = (PAIR ? 2 : 1) * BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128, PAIR) or 1 (BN 64) per wave
-  static constexpr int NSLOT = 3;
+  // ROW3 (BN = 64): a slot holds the three slabs of a tap ROW, and the ring has two slots (the next step's slabs are fetched
+  // during the current step)
+  static constexpr int W_BYTES = (ROW3 ? 3 : (PAIR ? 2 : 1)) * BN * 128, NDW = W_BYTES / 1024 / 8; // 2 (BN 128, PAIR), 3 (ROW3) or 1 (BN 64) per wave
+  static constexpr int NSLOT = ROW3 ? 2 : 3;
   // the weight ring sits FIRST: slot * W_BYTES (<= 32 KiB) then folds into the 16-bit offset field of the fragment
   // ds_reads (behind the patches, at 102 KiB, every read cost a v_add and the tap a spilled-SGPR v_readlane)
   static constexpr int W_BASE = 0;
@@ -956,10 +958,14 @@ struct CfgP {
 // (9 steps; step 4 straddles the chunks): one barrier, one counted wait and one DMA burst per 32 MFMAs, as in the
 // 128-channel kernel; a ring slot holds both taps' weight slabs (16 KiB, the 128-channel ring), the second tap's
 // fragments are fetched behind the first tap's MFMAs.  Same accumulation order, bit-identical outputs.
-template <int BN, bool BNBWD = false, bool PP = false, bool PAIR = false>
+// ROW3 (BN = 64, any number of chunks): a step = the three taps of one tap ROW (48 MFMAs per wave between barriers, three
+// steps per chunk); a two-slot weight ring, every wave issues its DMAs in front of its MFMAs (with this much work per step
+// the placement of the burst no longer matters: UNET_PDMA_STG 0 / 1 are +-0 on the pair kernel).
+template <int BN, bool BNBWD = false, bool PP = false, bool PAIR = false, bool ROW3 = false>
 __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   static_assert(!PAIR || (BN == 64 && !PP), "pair steps: the lock-step 64-channel kernel");
-  using C = CfgP<BN, PAIR>;
+  static_assert(!ROW3 || (BN == 64 && !PP && !PAIR), "row steps: the lock-step 64-channel kernel");
+  using C = CfgP<BN, PAIR, ROW3>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -1199,6 +1205,43 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
     mm(1, c3, g1);
   };
 
+  // ROW3: the slabs of taps 3r .. 3r+2 of `chunk` into ring slot `slot`; the three taps back to back, fragments two
+  // half-steps ahead of their MFMAs
+  auto dma_w3 = [&](unsigned wbase, int chunk, int r, int slot, bool live) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const unsigned soff = live ? wbase + (unsigned)(3 * r + j) * w_tap_stride + (unsigned)chunk * 128 : 0u;
+      char* dst = live ? smem + C::W_BASE + slot * C::W_BYTES + j * (BN * 128) + wave * 1024 : smem + C::DUMMY;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, live ? w_g[0] : OOB, soff, 0, 0);
+    }
+  };
+  auto compute3 = [&](int pbuf, int r, int slot) {
+    const char* pa = smem + C::W_BASE + slot * C::W_BYTES;
+    const char* pb = smem + pbuf + r * C::RS;
+    bf16x8 fbq[3][4], faq[3][2];
+    auto load = [&](int h, int q) {              // half-step h = 2 * tap + ks into fragment set q
+      const int tj = h >> 1, ks = h & 1;
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) fbq[q][pt] = *reinterpret_cast<const bf16x8*>(pb + tj * C::PSTR + boff[pt] + ks * 64);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) faq[q][ct] = *reinterpret_cast<const bf16x8*>(pa + tj * (BN * 128) + aoff[ct][ks]);
+    };
+    load(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(1, 1);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const int q = h % 3;
+      if (h + 2 < 6) load(h + 2, (h + 2) % 3);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(faq[q][ct], fbq[q][pt], acc[ct][pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   // PP: the same tap as two halves -- every fragment of the tap into registers, then nothing but MFMAs
   bf16x8 fa[2][C::CT], fb[2][4];
   auto load_frags = [&](int pbuf, int toff, int slot) {
@@ -1226,7 +1269,9 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   setup_dma(logical);
 #pragma unroll
   for (int j = 0; j < C::NDA; ++j) dma_patch(0, j, 0, true);
-  if constexpr (PAIR) {
+  if constexpr (ROW3) {
+    dma_w3(d_wbase, 0, 0, 0, true);
+  } else if constexpr (PAIR) {
     dma_w2(d_wbase, 0, 0, true);
     dma_w2(d_wbase, 2, 1, true);
   } else {
@@ -1245,6 +1290,7 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
   const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int pbuf_i = 0;                                 // patch buffer of the chunk being computed
+  int wslot = 0;                                  // ROW3: ring slot of the step being computed
   bool after_epilogue = false;
   const bool late_dma = !PP && P.pdma_stagger && __builtin_amdgcn_readfirstlane(wave) < 4;
   // BatchNorm partial sums of this lane's outputs (4 channels x CT tiles, 2 statistics).  Block mode (P.zdiv: every
@@ -1288,7 +1334,38 @@ __device__ __forceinline__ void conv3_pdma_body(const IgemmParams& P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[a][b][q] = 0.f;
 
-    if constexpr (PAIR) {
+    if constexpr (ROW3) {
+      // three steps (tap rows) per chunk.  W(step) was issued during the previous step, behind that step's patch pieces: the
+      // youngest operations in flight [+ the output stores of the previous item's epilogue] -> wait for everything older
+      for (int c = 0; c < nchunks; ++c) {
+        const bool last = c + 1 == nchunks;
+        if (last) {                                // from here on the DMA stream belongs to the next work item
+          d_live = has_next;
+          if (has_next) setup_dma(wk + G);
+        }
+        const int pbuf = C::A_BASE + pbuf_i * C::A_BYTES;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (r == 0 && c == 0 && after_epilogue) {
+            if (P.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NST) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          const int j0 = r == 0 ? 0 : (r == 1 ? 3 : 5), nj = r == 0 ? 3 : 2;       // patch pieces 0-2 | 3,4 | 5,6 of the next chunk
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (q < nj) dma_patch(last ? 0 : c + 1, j0 + q, pbuf_i ^ 1, last ? d_live : true);
+          if (r < 2) dma_w3(c_wbase, c, r + 1, wslot ^ 1, true);
+          else if (!last) dma_w3(c_wbase, c + 1, 0, wslot ^ 1, true);
+          else dma_w3(d_wbase, 0, 0, wslot ^ 1, d_live);
+          compute3(pbuf, r, wslot);
+          wslot ^= 1;
+        }
+        pbuf_i ^= 1;
+      }
+    } else if constexpr (PAIR) {
       // 9 steps of two taps; chunk 0 lives in patch buffer 0, chunk 1 in buffer 1 (nchunks == 2: the launcher's condition).
       // Patch pieces: steps 0-3 bring THIS item's chunk 1 (2, 2, 2, 1 pieces per wave), steps 5-8 the NEXT item's chunk 0
       // (buffer 0 is read for the last time by step 4); the weights of step d + 2 follow the pieces of step d.
@@ -1702,6 +1779,8 @@ __global__ __launch_bounds__(512, 1) void conv3_pp128_bnbwd_kernel(const IgemmPa
 __global__ __launch_bounds__(512, 1) void conv3_pp64_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma64x2_kernel(const IgemmParams P) { conv3_pdma_body<64, false, false, true>(P); }
 __global__ __launch_bounds__(512, 1) void conv3_pdma64x2_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, false, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64x3_kernel(const IgemmParams P) { conv3_pdma_body<64, false, false, false, true>(P); }
+__global__ __launch_bounds__(512, 1) void conv3_pdma64x3_bnbwd_kernel(const IgemmParams P) { conv3_pdma_body<64, true, false, false, true>(P); }
 
 #ifdef PDMA_STAMPS
 void* g_pdma_debug = nullptr;      // (also read by wgrad.hip)
@@ -1730,13 +1809,15 @@ int32_t launch_pdma(const IgemmParams& Pin, int kclass, hipStream_t s, int* stat
   const char ppv = unet_tuning().pdma_pp;
   const bool pp = ppv == '1' || (ppv != '0' && BN == 128 && P.Ctot >= 512);
   // two taps per step for 64-channel tiles over exactly two chunks (UNET_PDMA_PAIR=0: one tap per step, for A/B)
-  const bool pair = BN == 64 && !pp && P.Ctot == 128 && unet_tuning().pdma_pair != '0';
-  auto kern = pair ? (bnbwd ? conv3_pdma64x2_bnbwd_kernel : conv3_pdma64x2_kernel)
+  const bool row3 = BN == 64 && !pp && unet_tuning().pdma_pair == '3';          // UNET_PDMA_PAIR=3: a tap row per step (A/B)
+  const bool pair = BN == 64 && !pp && !row3 && P.Ctot == 128 && unet_tuning().pdma_pair != '0';
+  auto kern = row3 ? (bnbwd ? conv3_pdma64x3_bnbwd_kernel : conv3_pdma64x3_kernel)
+              : pair ? (bnbwd ? conv3_pdma64x2_bnbwd_kernel : conv3_pdma64x2_kernel)
               : pp ? (bnbwd ? (BN == 128 ? conv3_pp128_bnbwd_kernel : conv3_pp64_bnbwd_kernel)
                             : (BN == 128 ? conv3_pp128_kernel : conv3_pp64_kernel))
                    : (bnbwd ? (BN == 128 ? conv3_pdma128_bnbwd_kernel : conv3_pdma64_bnbwd_kernel)
                             : (BN == 128 ? conv3_pdma128_kernel : conv3_pdma64_kernel));
-  const int lds_bytes = pair ? CfgP<64, true>::LDS : C::LDS;
+  const int lds_bytes = row3 ? CfgP<64, false, true>::LDS : (pair ? CfgP<64, true>::LDS : C::LDS);
   unet_set_max_lds(reinterpret_cast<const void*>(kern), lds_bytes);
   const long long work = (long long)P.N * P.tilesY * P.tilesX * P.nCo;
   UNET_REQUIRE(work > 0 && work < (1LL << 30), UNET_ERR_UNSUPPORTED, "conv3_pdma: %lld work items", work);
