@@ -28,9 +28,10 @@ def main():
     p = lambda t: C.c_void_p(t.data_ptr())
     dt, DT = torch.bfloat16, L.UNET_BF16
     V = ops._views
-    if a.phase in ("conv512", "wgrad512", "conv64", "conv128"):
+    if a.phase in ("conv512", "wgrad512", "conv64", "conv128", "conv128_64", "wgrad64", "wgrad128_64", "conv1024_512"):
         n, ci, co, h = {"conv512": (32, 512, 512, 32), "wgrad512": (32, 512, 512, 32), "conv64": (32, 64, 64, 256),
-                        "conv128": (32, 128, 128, 128)}[a.phase]
+                        "conv128": (32, 128, 128, 128), "conv128_64": (32, 128, 64, 256), "wgrad64": (32, 64, 64, 256),
+                        "wgrad128_64": (32, 128, 64, 256), "conv1024_512": (32, 1024, 512, 32)}[a.phase]
         # post-ReLU-like operands (half zeros), as in the step
         x = torch.randn(n, ci, h, h, device=dev).clamp_min(0).to(dt).contiguous(memory_format=torch.channels_last)
         gy = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
@@ -41,7 +42,7 @@ def main():
         need = lib.unet_conv3x3_wgrad_workspace(n, h, h, ci, co)
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         flops = 2.0 * n * h * h * co * ci * 9
-        if a.phase == "wgrad512":
+        if a.phase.startswith("wgrad"):
             run = lambda: L.check(lib.unet_conv3x3_wgrad(DT, n, h, h, V([(x, 0, 0), None]), p(gy), co, p(dw), ci, p(ws), need, st), "wgrad")
         else:
             run = lambda: L.check(lib.unet_conv3x3(DT, n, h, h, V([(x, 0, 0), None]), p(wp), co, V([(y, 0, 0), None]), co, 0, 0, st), "fwd")

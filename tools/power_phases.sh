@@ -4,7 +4,7 @@
 out=gpurun_out/power_phases.log
 : > $out
 rocm-smi --showmaxpower 2>&1 | grep -E "Max Graphics" >> $out
-for phase in idle bn_apply bn_bwd conv64 conv128 conv512 wgrad512; do
+for phase in ${PHASES:-idle bn_apply bn_bwd conv64 conv128 conv512 wgrad512}; do
   echo "=== $phase" >> $out
   python3 tools/power_phase.py $phase --seconds 7 >> $out 2>/dev/null &
   pid=$!
