@@ -95,6 +95,7 @@ def _subgroup_worker(rank, world, port, out):
         group = dist.new_group([1, 2])
         if rank == 0:
             out[rank] = "idle"
+            dist.barrier()                         # (rank 0 hosts the rendezvous store: it must outlive the others' work)
             return
         net = _net(200 + rank)
         ddp = DataParallel(net, bucket_bytes=1024, process_group=group)
@@ -108,6 +109,7 @@ def _subgroup_worker(rank, world, port, out):
                 for p in net.parameters():
                     p -= 0.1 * p.grad
         out[rank] = [p.detach().clone() for p in net.parameters()]
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
